@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, loaded through oracle/ref_loader.py);
+the fixtures it writes are data: seeded inputs (or their sha256 when they are regenerated from
+hsc_amd.synth) and the reference's outputs.  Re-run with `python tools/make_golden.py`.
+
+Files written:
+  tests/golden/cmp_small.npz    -- ~40 small CMP cases (f32/f64, odd/even W, F>1, blocked selection,
+                                   weights, every stop rule): inputs + ordered (t,k,c) trace + CSC + residual
+  tests/golden/functions.npz    -- convolve1d ('same'/'valid'), _selectBestAtoms, _updateInnerProducts
+                                   (reflect padding at both edges) on seeded inputs
+  tests/golden/cmp_config.npz   -- BASELINE config 1 (T=4096) and 8 full-size config-2 signals
+                                   (T=65536, K=256, W=64, L0=256): outputs + input digests
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from refutil import run_reference_cmp, load_reference  # noqa: E402
+import hsc_amd.synth as synth  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def small_cases():
+    """(name, x, D, kwargs) tuples; all inputs from one seeded RandomState, in a fixed order."""
+    rs = np.random.RandomState(20261003)
+    norm = load_reference().utils.normalize
+    cases = []
+    for dt in (np.float32, np.float64):
+        tag = 'f32' if dt == np.float32 else 'f64'
+        # reference test shapes (tests/hsc/test_modeling.py:247-270): tiny T, odd/even W
+        for K in (1, 2, 3):
+            for W in (3, 5, 6):
+                D = norm(rs.random_sample((K, W)).astype(dt), axis=1)
+                x = rs.random_sample(16).astype(dt)
+                cases.append(('%s_T16_K%d_W%d_L4' % (tag, K, W), x, D, dict(nbNonzeroCoefs=4)))
+        D = norm(rs.random_sample((16, 15, 7)).astype(dt), axis=(1, 2))
+        x = rs.random_sample((64, 7)).astype(dt)
+        cases.append(('%s_T64_K16_W15_F7_L16' % tag, x, D, dict(nbNonzeroCoefs=16)))
+        # stop rules (test_modeling.py:329-360)
+        D = norm(rs.random_sample((32, 9)).astype(dt), axis=1)
+        x = rs.random_sample(128).astype(dt)
+        for tol in (0.5, 0.1, 0.001):
+            cases.append(('%s_T128_K32_W9_scale%g' % (tag, tol), x, D, dict(toleranceResidualScale=tol)))
+        for tol in (5, 20, 50):
+            cases.append(('%s_T128_K32_W9_snr%g' % (tag, tol), x, D, dict(toleranceSnr=tol)))
+        # features (test_modeling.py:362-377)
+        for F in (4, 11):
+            D3 = norm(rs.random_sample((32, 9, F)).astype(dt), axis=(1, 2))
+            x3 = rs.random_sample((128, F)).astype(dt)
+            cases.append(('%s_T128_K32_W9_F%d_scale0.01' % (tag, F), x3, D3, dict(toleranceResidualScale=0.01)))
+        # blocked selection, offsets, weights, interference / weak filters
+        D = norm(rs.standard_normal((24, 10)).astype(dt), axis=1)
+        x = rs.standard_normal(300).astype(dt)
+        for nb in (2, 4, 5, 8, 'auto'):
+            cases.append(('%s_T300_K24_W10_snr12_nb%s' % (tag, nb), x, D, dict(toleranceSnr=12, nbBlocks=nb)))
+        w = np.ones(24, dtype=dt)
+        w[:6] = 0.5
+        cases.append(('%s_T300_K24_W10_L30_weights' % tag, x, D, dict(nbNonzeroCoefs=30, weights=w)))
+        cases.append(('%s_T300_K24_W10_L30_nb4_weights' % tag, x, D, dict(nbNonzeroCoefs=30, nbBlocks=4, weights=w)))
+        cases.append(('%s_T300_K24_W10_snr15_auto_weights' % tag, x, D, dict(toleranceSnr=15, nbBlocks='auto', weights=w)))
+        # planted atoms (test_modeling.py:379-396 shape), minCoefficients clip
+        D = norm(rs.random_sample((4, 32)).astype(dt), axis=1)
+        x = np.zeros(256, dtype=np.float64)
+        for c, p, k in zip([1.0, 1.0, 0.5, 1.0, 0.75, 2.0], [32, 48, 64, 96, 128, 192], [0, 3, 1, 0, 2, 2]):
+            s, e, es, ee = synth.centered_span(256, 32, p)
+            x[s:e] += c * D[k][es:ee]
+        cases.append(('%s_planted_T256_K4_W32' % tag, x.astype(dt), D, dict(nbNonzeroCoefs=8, minCoefficients=1e-6)))
+        # atoms planted against both edges: reflect-padding quirk of the local update (modeling.py:1046)
+        D = norm(rs.standard_normal((8, 16)).astype(dt), axis=1)
+        x = (0.05 * rs.standard_normal(200)).astype(np.float64)
+        for c, p, k in zip([2.0, -1.5, 1.0, 3.0, -2.5], [2, 9, 100, 195, 199], [1, 5, 2, 7, 0]):
+            s, e, es, ee = synth.centered_span(200, 16, p)
+            x[s:e] += c * D[k][es:ee]
+        cases.append(('%s_edges_T200_K8_W16_L12' % tag, x.astype(dt), D, dict(nbNonzeroCoefs=12)))
+        # odd width at the edges
+        D = norm(rs.standard_normal((6, 9)).astype(dt), axis=1)
+        x = rs.standard_normal(40).astype(dt)
+        cases.append(('%s_T40_K6_W9_L25' % tag, x, D, dict(nbNonzeroCoefs=25)))
+    return cases
+
+
+def pack_csc(prefix, m, out):
+    m = m.tocoo()
+    order = np.lexsort((m.row, m.col))
+    out[prefix + '_row'] = m.row[order].astype(np.int32)
+    out[prefix + '_col'] = m.col[order].astype(np.int32)
+    out[prefix + '_data'] = m.data[order].astype(np.float64)
+
+
+def gen_small():
+    out = {}
+    names = []
+    for name, x, D, kw in small_cases():
+        coefficients, residual, tr = run_reference_cmp(x, D, **kw)
+        names.append(name)
+        out[name + '__x'] = x
+        out[name + '__D'] = D
+        for key, val in kw.items():
+            if key == 'weights':
+                out[name + '__weights'] = val
+            elif key == 'nbBlocks':
+                out[name + '__nbBlocks'] = np.array(-1 if val == 'auto' else val)
+            else:
+                out[name + '__' + key] = np.array(val)
+        out[name + '__t'] = tr['t']
+        out[name + '__k'] = tr['k']
+        out[name + '__c'] = np.asarray(tr['c'])
+        out[name + '__residual'] = residual
+        pack_csc(name + '__csc', coefficients, out)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'cmp_small.npz'), **out)
+    print('cmp_small.npz: %d cases' % len(names))
+
+
+def gen_functions():
+    ref = load_reference()
+    m = ref.modeling
+    norm = ref.utils.normalize
+    rs = np.random.RandomState(777)
+    out = {}
+    names = []
+    cmp = m.ConvolutionalMatchingPursuit()
+    for dt in (np.float32, np.float64):
+        tag = 'f32' if dt == np.float32 else 'f64'
+        for (T, K, W, F) in [(50, 5, 4, 1), (50, 5, 7, 1), (40, 6, 8, 3), (33, 4, 5, 2), (200, 16, 32, 1)]:
+            name = '%s_T%d_K%d_W%d_F%d' % (tag, T, K, W, F)
+            names.append(name)
+            D = norm(rs.standard_normal((K, W) if F == 1 else (K, W, F)).astype(dt), axis=tuple(range(1, 2 if F == 1 else 3)))
+            x = rs.standard_normal((T,) if F == 1 else (T, F)).astype(dt)
+            out[name + '__x'] = x
+            out[name + '__D'] = D
+            ip = m.convolve1d(x, D, padding='same')
+            out[name + '__same'] = ip
+            out[name + '__valid'] = m.convolve1d(x, D, padding='valid')
+            # _selectBestAtoms on the reference's table, several modes (modeling.py:899-982)
+            w = (0.25 + rs.random_sample(K)).astype(dt)
+            modes = [(1, False, None), (1, False, w), (2, False, None), (2, True, None), (3, True, w),
+                     (5, False, None), (5, True, None), ('auto', False, None), ('auto', True, w)]
+            for i, (nb, off, ww) in enumerate(modes):
+                atoms = cmp._selectBestAtoms(ip, W, nbBlocks=nb, offset=off, nullCoeffThres=1e-16, weights=ww)
+                out['%s__sel%d_nb' % (name, i)] = np.array(-1 if nb == 'auto' else nb)
+                out['%s__sel%d_offset' % (name, i)] = np.array(int(off))
+                if ww is not None:
+                    out['%s__sel%d_weights' % (name, i)] = ww
+                out['%s__sel%d_t' % (name, i)] = np.array([a.position for a in atoms], dtype=np.int32)
+                out['%s__sel%d_k' % (name, i)] = np.array([a.index for a in atoms], dtype=np.int32)
+                out['%s__sel%d_c' % (name, i)] = np.array([a.coefficient for a in atoms], dtype=dt)
+            out[name + '__nsel'] = np.array(len(modes))
+            # _updateInnerProducts at both edges and in the interior (modeling.py:1018-1051):
+            # perturb the residual on the atom's support (as a subtraction would), then let the
+            # reference refresh the table
+            positions = [0, 1, W // 2, T // 2, T - 2, T - 1]
+            r = x.copy()
+            ip2 = ip.copy()
+            for j, p in enumerate(positions):
+                atom = m.Atom(p, 0, 1.0, W)
+                r2 = r.copy()
+                s, e, es, ee = synth.centered_span(T, W, p)
+                r2[s:e] += (0.5 * rs.standard_normal(r2[s:e].shape)).astype(dt)
+                r = r2
+                ip2 = cmp._updateInnerProducts(ip2, r.reshape((T, -1)), [atom], D.reshape((K, W, -1)))
+                out['%s__upd%d_p' % (name, j)] = np.array(p)
+                out['%s__upd%d_r' % (name, j)] = r.copy()
+                out['%s__upd%d_ip' % (name, j)] = ip2.copy()
+            out[name + '__nupd'] = np.array(len(positions))
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'functions.npz'), **out)
+    print('functions.npz: %d cases' % len(names))
+
+
+def gen_config():
+    out = {}
+    # config 1 (scripts/demo_csc.py-sized): T=4096, K=32, W=32, L0=64, f32, planted + noise
+    D1 = synth.make_dictionary(32, 32, seed=1)
+    out['config1__D_digest'] = np.array(synth.digest(D1))
+    for kind in ('planted', 'noise'):
+        x = synth.make_signal(D1, 4096, 0, kind=kind, nb_atoms=64, seed=1)
+        t0 = time.time()
+        coefficients, residual, tr = run_reference_cmp(x, D1, nbNonzeroCoefs=64)
+        name = 'config1_%s' % kind
+        out[name + '__x_digest'] = np.array(synth.digest(x))
+        out[name + '__t'] = tr['t']; out[name + '__k'] = tr['k']; out[name + '__c'] = np.asarray(tr['c'])
+        out[name + '__residual_energy'] = np.array(float(np.sum(np.square(residual.astype(np.float64)))))
+        pack_csc(name + '__csc', coefficients, out)
+        print(name, 'ref time %.2fs' % (time.time() - t0), 'n', len(tr['t']))
+    # config 2: full size, 4 planted + 4 noise signals
+    D2 = synth.make_dictionary(256, 64, seed=2)
+    out['config2__D_digest'] = np.array(synth.digest(D2))
+    for kind in ('planted', 'noise'):
+        for idx in range(4):
+            x = synth.make_signal(D2, 65536, idx, kind=kind, nb_atoms=256, seed=2)
+            t0 = time.time()
+            coefficients, residual, tr = run_reference_cmp(x, D2, nbNonzeroCoefs=256)
+            name = 'config2_%s_%d' % (kind, idx)
+            out[name + '__x_digest'] = np.array(synth.digest(x))
+            out[name + '__t'] = tr['t']; out[name + '__k'] = tr['k']; out[name + '__c'] = np.asarray(tr['c'])
+            out[name + '__residual_energy'] = np.array(float(np.sum(np.square(residual.astype(np.float64)))))
+            pack_csc(name + '__csc', coefficients, out)
+            print(name, 'ref time %.2fs' % (time.time() - t0), 'n', len(tr['t']))
+    np.savez_compressed(os.path.join(OUT, 'cmp_config.npz'), **out)
+
+
+if __name__ == '__main__':
+    assert load_reference() is not None, 'the reference is not available in this environment'
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['small', 'functions', 'config']
+    if 'small' in which:
+        gen_small()
+    if 'functions' in which:
+        gen_functions()
+    if 'config' in which:
+        gen_config()
