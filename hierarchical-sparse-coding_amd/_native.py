@@ -1,0 +1,269 @@
+"""ctypes binding of libhscmp.so (C ABI: include/hscmp.h).
+
+There is no CPU implementation behind this module: if the shared library has not been built, or
+no MI355X is visible, every entry point raises.  Build with `python __graft_entry__.py build` or
+`make -C hierarchical-sparse-coding_amd/csrc`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libhscmp.so')
+
+F32, F64 = 0, 1
+STAT_NNZ, STAT_DUPLICATES, STAT_ROUNDS, STAT_STOP, STAT_ITERATIONS, STAT_EVENTS, STAT_SLOTS, STAT_OFFSET = range(8)
+STAT_COUNT = 8
+STOP_NAMES = {0: 'running', 1: 'energy_eps', 2: 'nnz', 3: 'snr', 4: 'residual_scale', 5: 'empty',
+              6: 'callback', 7: 'capacity'}
+STOP_RUNNING, STOP_CAPACITY = 0, 7
+
+# every symbol include/hscmp.h declares (checked by tests/test_abi.py)
+EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
+           'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_encode_batch',
+           'hscmp_encode_batch_device', 'hscmp_continue', 'hscmp_stop_signal', 'hscmp_fetch_events',
+           'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
+           'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
+
+
+class HscmpParams(ctypes.Structure):
+    _fields_ = [('nb_nonzero_coefs', ctypes.c_int32),
+                ('nb_blocks', ctypes.c_int32),
+                ('tolerance_snr', ctypes.c_double),
+                ('tolerance_residual_scale', ctypes.c_double),
+                ('null_coeff_thres', ctypes.c_double),
+                ('eps', ctypes.c_double),
+                ('max_events', ctypes.c_int32),
+                ('max_rounds', ctypes.c_int32)]
+
+
+class HscmpDeviceView(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('T', ctypes.c_int32), ('F', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('W', ctypes.c_int32), ('max_events', ctypes.c_int32), ('dtype', ctypes.c_int32),
+                ('reserved', ctypes.c_int32),
+                ('ev_t', ctypes.c_void_p), ('ev_k', ctypes.c_void_p), ('ev_c', ctypes.c_void_p),
+                ('stats', ctypes.c_void_p), ('residual', ctypes.c_void_p), ('energies', ctypes.c_void_p),
+                ('best_c', ctypes.c_void_p), ('best_k', ctypes.c_void_p)]
+
+
+class HscmpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libhscmp.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HscmpError('libhscmp.so is not built (%s). Run `python __graft_entry__.py build` '
+                         '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.hscmp_version.restype = ci
+    lib.hscmp_create.argtypes = [ctypes.POINTER(vp), ci]
+    lib.hscmp_destroy.argtypes = [vp]
+    lib.hscmp_destroy.restype = None
+    lib.hscmp_last_error.argtypes = [vp]
+    lib.hscmp_last_error.restype = ctypes.c_char_p
+    lib.hscmp_set_stream.argtypes = [vp, vp]
+    lib.hscmp_synchronize.argtypes = [vp]
+    lib.hscmp_set_dictionary.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    lib.hscmp_convolve1d.argtypes = [vp, vp, ci, ci, vp]
+    lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
+    lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
+    lib.hscmp_continue.argtypes = [vp, ci]
+    lib.hscmp_stop_signal.argtypes = [vp, ci]
+    lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
+    lib.hscmp_fetch_stats.argtypes = [vp, vp]
+    lib.hscmp_fetch_residual.argtypes = [vp, vp]
+    lib.hscmp_fetch_energies.argtypes = [vp, vp]
+    lib.hscmp_fetch_slots.argtypes = [vp, vp, vp, vp]
+    lib.hscmp_get_device_view.argtypes = [vp, ctypes.POINTER(HscmpDeviceView)]
+    lib.hscmp_last_kernel_ms.argtypes = [vp, vp]
+    lib.hscmp_last_variant.argtypes = [vp]
+    lib.hscmp_last_variant.restype = ctypes.c_char_p
+    for name in EXPORTS:   # also asserts that every declared symbol is exported
+        fn = getattr(lib, name)
+        if name not in ('hscmp_destroy', 'hscmp_last_error', 'hscmp_last_variant'):
+            fn.restype = ci
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return F32
+    if dtype == np.float64:
+        return F64
+    raise TypeError('the engine computes in float32 or float64, got %s' % dtype)
+
+
+def nb_blocks_code(nbBlocks):
+    if isinstance(nbBlocks, str):
+        if nbBlocks != 'auto':
+            raise ValueError("nbBlocks must be an integer >= 1 or 'auto'")
+        return -1
+    nb = int(nbBlocks)
+    if nb < 1:
+        raise ValueError("nbBlocks must be an integer >= 1 or 'auto'")
+    return nb
+
+
+def make_params(nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None, nbBlocks=1,
+                minCoefficients=1e-16, eps=None, maxEvents=4096, maxRounds=0):
+    nan = float('nan')
+    return HscmpParams(
+        nb_nonzero_coefs=-1 if nbNonzeroCoefs is None else int(nbNonzeroCoefs),
+        nb_blocks=nb_blocks_code(nbBlocks),
+        tolerance_snr=nan if toleranceSnr is None else float(toleranceSnr),
+        tolerance_residual_scale=nan if toleranceResidualScale is None else float(toleranceResidualScale),
+        null_coeff_thres=nan if minCoefficients is None else float(minCoefficients),
+        eps=float(eps), max_events=int(maxEvents), max_rounds=int(maxRounds))
+
+
+class Engine(object):
+    """One GPU context (hscmp_ctx): resident dictionary + batch workspace."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.hscmp_create(ctypes.byref(h), int(device))
+        if rc != 0:
+            raise HscmpError('hscmp_create failed (%d): %s' % (rc, self._lib.hscmp_last_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+        self.dtype = None
+        self.K = self.W = self.F = None
+        self._batch = None
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.hscmp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HscmpError('%s failed (%d): %s' % (what, rc, self._lib.hscmp_last_error(self._h).decode()))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.hscmp_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), 'hscmp_set_stream')
+
+    def synchronize(self):
+        self._check(self._lib.hscmp_synchronize(self._h), 'hscmp_synchronize')
+
+    def set_dictionary(self, D, weights=None):
+        """D [K,W] or [K,W,F] float32/float64 (C order); weights [K] or None."""
+        assert D.ndim in (2, 3)
+        D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)))
+        code = dtype_code(D3.dtype)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=D3.dtype)
+        if w is not None and w.shape != (D3.shape[0],):
+            raise ValueError('weights must have one entry per atom')
+        K, W, F = D3.shape
+        self._check(self._lib.hscmp_set_dictionary(self._h, _ptr(D3), K, W, F, code, _ptr(w)), 'hscmp_set_dictionary')
+        self.dtype, self.K, self.W, self.F = D3.dtype, K, W, F
+        self._batch = None
+
+    def convolve1d(self, x, same):
+        x2 = np.ascontiguousarray(x.reshape((x.shape[0], -1)), dtype=self.dtype)
+        assert x2.shape[1] == self.F
+        T = x2.shape[0]
+        Tout = T if same else T - self.W + 1
+        if Tout <= 0:
+            raise HscmpError('sequence shorter than the filters')
+        out = np.empty((Tout, self.K), dtype=self.dtype)
+        self._check(self._lib.hscmp_convolve1d(self._h, _ptr(x2), T, 1 if same else 0, _ptr(out)), 'hscmp_convolve1d')
+        return out
+
+    def encode_batch(self, x, params):
+        """x [B,T,F] host array of the dictionary dtype."""
+        x3 = np.ascontiguousarray(x, dtype=self.dtype)
+        assert x3.ndim == 3 and x3.shape[2] == self.F
+        B, T = x3.shape[0], x3.shape[1]
+        self._check(self._lib.hscmp_encode_batch(self._h, _ptr(x3), B, T, ctypes.byref(params)), 'hscmp_encode_batch')
+        self._batch = (B, T, int(params.max_events))
+
+    def encode_batch_device(self, x_dev_ptr, B, T, params):
+        """x_dev_ptr: device address of [B,T,F] in the dictionary dtype; asynchronous."""
+        self._check(self._lib.hscmp_encode_batch_device(self._h, ctypes.c_void_p(x_dev_ptr), int(B), int(T),
+                                                        ctypes.byref(params)), 'hscmp_encode_batch_device')
+        self._batch = (int(B), int(T), int(params.max_events))
+
+    def continue_rounds(self, max_rounds):
+        self._check(self._lib.hscmp_continue(self._h, int(max_rounds)), 'hscmp_continue')
+
+    def stop_signal(self, b):
+        self._check(self._lib.hscmp_stop_signal(self._h, int(b)), 'hscmp_stop_signal')
+
+    def fetch_stats(self):
+        B = self._batch[0]
+        st = np.empty((B, STAT_COUNT), dtype=np.int32)
+        self._check(self._lib.hscmp_fetch_stats(self._h, _ptr(st)), 'hscmp_fetch_stats')
+        return st
+
+    def fetch_events(self):
+        B, _, cap = self._batch
+        t = np.empty((B, cap), dtype=np.int32)
+        k = np.empty((B, cap), dtype=np.int32)
+        c = np.empty((B, cap), dtype=self.dtype)
+        self._check(self._lib.hscmp_fetch_events(self._h, _ptr(t), _ptr(k), _ptr(c)), 'hscmp_fetch_events')
+        return t, k, c
+
+    def fetch_slots(self):
+        B, _, cap = self._batch
+        t = np.empty((B, cap), dtype=np.int32)
+        k = np.empty((B, cap), dtype=np.int32)
+        a = np.empty((B, cap), dtype=np.float64)
+        self._check(self._lib.hscmp_fetch_slots(self._h, _ptr(t), _ptr(k), _ptr(a)), 'hscmp_fetch_slots')
+        return t, k, a
+
+    def fetch_residual(self):
+        B, T, _ = self._batch
+        r = np.empty((B, T, self.F), dtype=self.dtype)
+        self._check(self._lib.hscmp_fetch_residual(self._h, _ptr(r)), 'hscmp_fetch_residual')
+        return r
+
+    def fetch_energies(self):
+        B = self._batch[0]
+        e = np.empty((B, 2), dtype=np.float64)
+        self._check(self._lib.hscmp_fetch_energies(self._h, _ptr(e)), 'hscmp_fetch_energies')
+        return e
+
+    def device_view(self):
+        v = HscmpDeviceView()
+        self._check(self._lib.hscmp_get_device_view(self._h, ctypes.byref(v)), 'hscmp_get_device_view')
+        return v
+
+    def last_kernel_ms(self):
+        out = np.zeros(4, dtype=np.float32)
+        self._check(self._lib.hscmp_last_kernel_ms(self._h, _ptr(out)), 'hscmp_last_kernel_ms')
+        return out
+
+    def last_variant(self):
+        return self._lib.hscmp_last_variant(self._h).decode()
+
+
+_engines = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine per device (the dictionary is re-uploaded when it changes)."""
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

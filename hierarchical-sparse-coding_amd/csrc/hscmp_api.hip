@@ -1,0 +1,506 @@
+// hscmp_api.hip -- host side of libhscmp.so (C ABI declared in include/hscmp.h).
+//
+// Owns the GPU-resident dictionary and the per-batch workspace (table-free state, event lists),
+// translates the reference's keyword arguments (hsc/modeling.py:1053) into kernel parameters and
+// queues prepare -> initial correlation -> greedy loop on one HIP stream.  No CPU compute path:
+// every entry point either runs the HIP kernels or fails with an error code.
+#include "../../include/hscmp.h"
+
+#include "hscmp_kernels.h"
+#include "hscmp_mfma.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace hscmp;
+
+struct hscmp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string variant = "none";
+    // dictionary
+    int K = 0, W = 0, F = 0, dtype = -1;
+    void* d_D = nullptr;
+    void* d_w = nullptr;      // nullptr when no weights
+    void* d_Dfrag = nullptr;  // MFMA fragment-ordered copy (f32, F == 1)
+    size_t Dfrag_bytes = 0;
+    // batch workspace
+    int B = 0, T = 0, cap = 0, maxsel = 0;
+    bool have_batch = false;
+    size_t cap_resid = 0, cap_best = 0, cap_ev = 0, cap_sel = 0, cap_stats = 0, cap_x = 0;
+    void* d_x = nullptr;      // staging for host inputs
+    void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
+    int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
+    int* d_slot_t = nullptr; int* d_slot_k = nullptr; double* d_slot_a = nullptr;
+    int* d_sel_t = nullptr; int* d_sel_k = nullptr; void* d_sel_c = nullptr;
+    int* d_stats = nullptr; void* d_energy = nullptr;
+    DevParams P{};
+    hscmp_params last{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+};
+
+static thread_local std::string g_err;
+
+static int fail(hscmp_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(ctx, HSCMP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+static size_t esize(int dtype) { return dtype == HSCMP_F64 ? 8 : 4; }
+
+extern "C" int hscmp_version(void) { return HSCMP_VERSION; }
+
+extern "C" const char* hscmp_last_error(hscmp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
+{
+    if (!out) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, HSCMP_ERR_NO_DEVICE, "hscmp_create: no HIP device visible (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_create: device %d out of range (%d devices)", device_id, n);
+    hscmp_ctx* ctx = new hscmp_ctx();
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, HSCMP_ERR_HIP, "hscmp_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return HSCMP_OK;
+}
+
+static void free_all(hscmp_ctx* c)
+{
+    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
+                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+
+extern "C" void hscmp_destroy(hscmp_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int hscmp_set_stream(hscmp_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_set_stream: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_synchronize(hscmp_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_synchronize: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W, int F, hscmp_dtype dtype, const void* weights)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_set_dictionary: ctx is NULL");
+    if (!D || K <= 0 || W <= 0 || F <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad shape K=%d W=%d F=%d", K, W, F);
+    if (dtype != HSCMP_F32 && dtype != HSCMP_F64) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad dtype %d", (int)dtype);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t es = esize(dtype);
+    const size_t nD = (size_t)K * W * F * es;
+    if (ctx->d_D) { (void)hipFree(ctx->d_D); ctx->d_D = nullptr; }
+    if (ctx->d_w) { (void)hipFree(ctx->d_w); ctx->d_w = nullptr; }
+    if (ctx->d_Dfrag) { (void)hipFree(ctx->d_Dfrag); ctx->d_Dfrag = nullptr; ctx->Dfrag_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_D, nD));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_D, D, nD, hipMemcpyHostToDevice));
+    if (weights) {
+        HIP_TRY(ctx, hipMalloc(&ctx->d_w, (size_t)K * es));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_w, weights, (size_t)K * es, hipMemcpyHostToDevice));
+    }
+    ctx->K = K; ctx->W = W; ctx->F = F; ctx->dtype = dtype;
+    ctx->have_batch = false;
+    // MFMA operand image of the dictionary (f32 only): built once, reused by every encode
+    if (dtype == HSCMP_F32 && mfma_supported(K, W, F)) {
+        std::vector<float> frag;
+        mfma_build_dict_image((const float*)D, K, W, F, frag);
+        ctx->Dfrag_bytes = frag.size() * sizeof(float);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Dfrag, ctx->Dfrag_bytes));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Dfrag, frag.data(), ctx->Dfrag_bytes, hipMemcpyHostToDevice));
+    }
+    return HSCMP_OK;
+}
+
+template <typename T> static int grow(hscmp_ctx* ctx, T** p, size_t* cap, size_t bytes)
+{
+    if (*p && *cap >= bytes) return HSCMP_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    *cap = bytes;
+    return HSCMP_OK;
+}
+
+static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevParams* out)
+{
+    DevParams P{};
+    P.B = B; P.T = T; P.K = ctx->K; P.W = ctx->W; P.F = ctx->F;
+    P.off = (ctx->W - 1) / 2;
+    int seg = 64;
+    while ((T + seg - 1) / seg > kMaxSeg) seg <<= 1;
+    P.seg = seg; P.nseg = (T + seg - 1) / seg;
+    if (p->nb_blocks == 1) { P.blocked = 0; P.bs = 0; P.nbk = 0; P.maxsel = 1; }
+    else {
+        // modeling.py:908-918
+        int bs;
+        if (p->nb_blocks < 0) bs = 4 * ctx->W;
+        else if (p->nb_blocks > 1) bs = (int)std::floor((double)T / (double)p->nb_blocks);
+        else return fail(ctx, HSCMP_ERR_INVALID, "nb_blocks must be 1, > 1 or -1 ('auto'), got %d", p->nb_blocks);
+        if (bs % 2 == 1) bs += 1;
+        if (bs <= 0) return fail(ctx, HSCMP_ERR_INVALID, "nbBlocks=%d gives an empty block for T=%d", p->nb_blocks, T);
+        P.blocked = 1; P.bs = bs; P.nbk = (int)std::ceil((double)T / (double)bs); P.maxsel = P.nbk + 1;
+    }
+    P.l0 = p->nb_nonzero_coefs < 0 ? -1 : p->nb_nonzero_coefs;
+    P.has_snr = !std::isnan(p->tolerance_snr);
+    P.has_scale = !std::isnan(p->tolerance_residual_scale);
+    P.has_thres = !std::isnan(p->null_coeff_thres);
+    P.snr_ratio = P.has_snr ? std::pow(10.0, p->tolerance_snr / 10.0) : 0.0;
+    P.tol_scale = P.has_scale ? p->tolerance_residual_scale : 0.0;
+    P.thres = P.has_thres ? p->null_coeff_thres : 0.0;
+    P.eps = p->eps;
+    if (p->max_events <= 0) return fail(ctx, HSCMP_ERR_INVALID, "max_events must be > 0");
+    P.cap = p->max_events;
+    P.max_rounds = p->max_rounds;
+    *out = P;
+    return HSCMP_OK;
+}
+
+static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
+{
+    const size_t es = esize(ctx->dtype);
+    const size_t B = P.B, TF = (size_t)P.T * P.F, T = P.T, cap = P.cap, ms = P.maxsel;
+    int rc;
+    size_t c;
+    if (need_x && (rc = grow(ctx, (char**)&ctx->d_x, &ctx->cap_x, B * TF * es))) return rc;
+    if ((rc = grow(ctx, (char**)&ctx->d_resid, &ctx->cap_resid, B * TF * es))) return rc;
+    // best_c / best_k share one capacity counter: grow both when either is short
+    if (!ctx->d_best_c || ctx->cap_best < B * T) {
+        if (ctx->d_best_c) { (void)hipFree(ctx->d_best_c); ctx->d_best_c = nullptr; }
+        if (ctx->d_best_k) { (void)hipFree(ctx->d_best_k); ctx->d_best_k = nullptr; }
+        c = 0; if ((rc = grow(ctx, (char**)&ctx->d_best_c, &c, B * T * es))) return rc;
+        c = 0; if ((rc = grow(ctx, &ctx->d_best_k, &c, B * T * sizeof(int)))) return rc;
+        ctx->cap_best = B * T;
+    }
+    if (!ctx->d_ev_t || ctx->cap_ev < B * cap) {
+        void** ps[] = {(void**)&ctx->d_ev_t, (void**)&ctx->d_ev_k, (void**)&ctx->d_ev_c, (void**)&ctx->d_slot_t, (void**)&ctx->d_slot_k, (void**)&ctx->d_slot_a};
+        size_t sz[] = {4, 4, es, 4, 4, 8};
+        for (int i = 0; i < 6; ++i) {
+            if (*ps[i]) { (void)hipFree(*ps[i]); *ps[i] = nullptr; }
+            c = 0; if ((rc = grow(ctx, (char**)ps[i], &c, B * cap * sz[i]))) return rc;
+        }
+        ctx->cap_ev = B * cap;
+    }
+    if (!ctx->d_sel_t || ctx->cap_sel < B * 2 * ms) {
+        void** ps[] = {(void**)&ctx->d_sel_t, (void**)&ctx->d_sel_k, (void**)&ctx->d_sel_c};
+        size_t sz[] = {4, 4, es};
+        for (int i = 0; i < 3; ++i) {
+            if (*ps[i]) { (void)hipFree(*ps[i]); *ps[i] = nullptr; }
+            c = 0; if ((rc = grow(ctx, (char**)ps[i], &c, B * 2 * ms * sz[i]))) return rc;
+        }
+        ctx->cap_sel = B * 2 * ms;
+    }
+    if (!ctx->d_stats || ctx->cap_stats < B) {
+        if (ctx->d_stats) { (void)hipFree(ctx->d_stats); ctx->d_stats = nullptr; }
+        if (ctx->d_energy) { (void)hipFree(ctx->d_energy); ctx->d_energy = nullptr; }
+        c = 0; if ((rc = grow(ctx, &ctx->d_stats, &c, B * ST_COUNT * sizeof(int)))) return rc;
+        c = 0; if ((rc = grow(ctx, (char**)&ctx->d_energy, &c, B * 2 * es))) return rc;
+        ctx->cap_stats = B;
+    }
+    return HSCMP_OK;
+}
+
+template <typename R> static State<R> make_state(hscmp_ctx* c)
+{
+    State<R> S;
+    S.D = (const R*)c->d_D; S.weights = (const R*)c->d_w;
+    S.residual = (R*)c->d_resid; S.best_c = (R*)c->d_best_c; S.best_k = c->d_best_k;
+    S.ev_t = c->d_ev_t; S.ev_k = c->d_ev_k; S.ev_c = (R*)c->d_ev_c;
+    S.slot_t = c->d_slot_t; S.slot_k = c->d_slot_k; S.slot_a = c->d_slot_a;
+    S.sel_t = c->d_sel_t; S.sel_k = c->d_sel_k; S.sel_c = (R*)c->d_sel_c;
+    S.stats = c->d_stats; S.energy = (R*)c->d_energy;
+    return S;
+}
+
+static bool use_mfma(const hscmp_ctx* ctx)
+{
+    if (getenv("HSCMP_FORCE_GENERIC")) return false;
+    return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr;
+}
+
+template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams& P)
+{
+    State<R> S = make_state<R>(ctx);
+    hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S);
+    return HSCMP_OK;
+}
+
+template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, const void* x_dev)
+{
+    State<R> S = make_state<R>(ctx);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    bool mf = false;
+    if (sizeof(R) == 4 && use_mfma(ctx)) {
+        int rc = mfma_launch_corr_init(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
+        if (rc == 0) mf = true;
+    }
+    if (!mf) {
+        dim3 grid((P.T + kThreads - 1) / kThreads, P.B);
+        hipLaunchKernelGGL((corr_init_generic_kernel<R, false>), grid, dim3(kThreads), 0, ctx->stream, P, S,
+                           (const R*)ctx->d_resid, P.off, P.T, (R*)nullptr);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    bool mfi = false;
+    if (sizeof(R) == 4 && use_mfma(ctx)) {
+        int rc = mfma_launch_iterate(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
+        if (rc == 0) mfi = true;
+    }
+    if (!mfi) launch_iterate<R>(ctx, P);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->timed = true;
+    ctx->variant = std::string(mf ? "mfma" : "generic") + "_init+" + (mfi ? "mfma" : "generic") + "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
+    return HSCMP_OK;
+}
+
+static int encode_common(hscmp_ctx* ctx, const void* x, bool host, int B, int T, const hscmp_params* params)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_encode_batch: ctx is NULL");
+    if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_encode_batch: no dictionary set");
+    if (!x || !params || B <= 0 || T <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_encode_batch: bad arguments (B=%d T=%d)", B, T);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevParams P;
+    int rc = make_params(ctx, B, T, params, &P);
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, P, host))) return rc;
+    const void* xd = x;
+    if (host) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_x, x, (size_t)B * T * ctx->F * esize(ctx->dtype), hipMemcpyHostToDevice, ctx->stream));
+        xd = ctx->d_x;
+    }
+    ctx->P = P; ctx->last = *params; ctx->B = B; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
+    rc = ctx->dtype == HSCMP_F32 ? run_encode<float>(ctx, P, xd) : run_encode<double>(ctx, P, xd);
+    if (rc) return rc;
+    ctx->have_batch = true;
+    if (host) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_encode_batch(hscmp_ctx* ctx, const void* x, int B, int T, const hscmp_params* params)
+{
+    return encode_common(ctx, x, true, B, T, params);
+}
+
+extern "C" int hscmp_encode_batch_device(hscmp_ctx* ctx, const void* x_dev, int B, int T, const hscmp_params* params)
+{
+    return encode_common(ctx, x_dev, false, B, T, params);
+}
+
+extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_continue: ctx is NULL");
+    if (!ctx->have_batch) return fail(ctx, HSCMP_ERR_STATE, "hscmp_continue: no batch encoded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevParams P = ctx->P;
+    P.max_rounds = max_rounds;
+    bool mfi = false;
+    if (ctx->dtype == HSCMP_F32 && use_mfma(ctx)) {
+        State<float> S = make_state<float>(ctx);
+        if (mfma_launch_iterate(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
+    }
+    if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_stop_signal(hscmp_ctx* ctx, int b)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_stop_signal: ctx is NULL");
+    if (!ctx->have_batch || b < 0 || b >= ctx->B) return fail(ctx, HSCMP_ERR_STATE, "hscmp_stop_signal: bad signal index %d", b);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int v = STOP_CALLBACK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int cur = 0;
+    HIP_TRY(ctx, hipMemcpy(&cur, ctx->d_stats + (size_t)b * ST_COUNT + ST_STOP, sizeof(int), hipMemcpyDeviceToHost));
+    if (cur == STOP_RUNNING)
+        HIP_TRY(ctx, hipMemcpy(ctx->d_stats + (size_t)b * ST_COUNT + ST_STOP, &v, sizeof(int), hipMemcpyHostToDevice));
+    return HSCMP_OK;
+}
+
+static int fetch(hscmp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!dst) return HSCMP_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return HSCMP_OK;
+}
+
+#define NEED_BATCH(ctx, name)                                                                   \
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, name ": ctx is NULL");                    \
+    if (!ctx->have_batch) return fail(ctx, HSCMP_ERR_STATE, name ": no batch encoded");         \
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+extern "C" int hscmp_fetch_events(hscmp_ctx* ctx, int32_t* ev_t, int32_t* ev_k, void* ev_c)
+{
+    NEED_BATCH(ctx, "hscmp_fetch_events");
+    const size_t n = (size_t)ctx->B * ctx->cap;
+    int rc;
+    if ((rc = fetch(ctx, ev_t, ctx->d_ev_t, n * 4))) return rc;
+    if ((rc = fetch(ctx, ev_k, ctx->d_ev_k, n * 4))) return rc;
+    if ((rc = fetch(ctx, ev_c, ctx->d_ev_c, n * esize(ctx->dtype)))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_fetch_slots(hscmp_ctx* ctx, int32_t* slot_t, int32_t* slot_k, double* slot_acc)
+{
+    NEED_BATCH(ctx, "hscmp_fetch_slots");
+    const size_t n = (size_t)ctx->B * ctx->cap;
+    int rc;
+    if ((rc = fetch(ctx, slot_t, ctx->d_slot_t, n * 4))) return rc;
+    if ((rc = fetch(ctx, slot_k, ctx->d_slot_k, n * 4))) return rc;
+    if ((rc = fetch(ctx, slot_acc, ctx->d_slot_a, n * 8))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_fetch_stats(hscmp_ctx* ctx, int32_t* stats)
+{
+    NEED_BATCH(ctx, "hscmp_fetch_stats");
+    int rc = fetch(ctx, stats, ctx->d_stats, (size_t)ctx->B * ST_COUNT * sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_fetch_residual(hscmp_ctx* ctx, void* residual)
+{
+    NEED_BATCH(ctx, "hscmp_fetch_residual");
+    int rc = fetch(ctx, residual, ctx->d_resid, (size_t)ctx->B * ctx->T * ctx->F * esize(ctx->dtype));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_fetch_energies(hscmp_ctx* ctx, double* energies)
+{
+    NEED_BATCH(ctx, "hscmp_fetch_energies");
+    if (!energies) return HSCMP_OK;
+    const size_t n = (size_t)ctx->B * 2;
+    if (ctx->dtype == HSCMP_F64) {
+        int rc = fetch(ctx, energies, ctx->d_energy, n * 8);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        std::vector<float> tmp(n);
+        int rc = fetch(ctx, tmp.data(), ctx->d_energy, n * 4);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; ++i) energies[i] = (double)tmp[i];
+    }
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_get_device_view(hscmp_ctx* ctx, hscmp_device_view* v)
+{
+    NEED_BATCH(ctx, "hscmp_get_device_view");
+    if (!v) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_get_device_view: view is NULL");
+    v->B = ctx->B; v->T = ctx->T; v->F = ctx->F; v->K = ctx->K; v->W = ctx->W; v->max_events = ctx->cap;
+    v->dtype = ctx->dtype; v->reserved = 0;
+    v->ev_t = ctx->d_ev_t; v->ev_k = ctx->d_ev_k; v->ev_c = ctx->d_ev_c; v->stats = ctx->d_stats;
+    v->residual = ctx->d_resid; v->energies = ctx->d_energy; v->best_c = ctx->d_best_c; v->best_k = ctx->d_best_k;
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4)
+{
+    if (!ctx || !out4) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_last_kernel_ms: NULL argument");
+    if (!ctx->timed) return fail(ctx, HSCMP_ERR_STATE, "hscmp_last_kernel_ms: nothing timed yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(&out4[i], ctx->ev[i], ctx->ev[i + 1]));
+    out4[3] = 0.f;
+    return HSCMP_OK;
+}
+
+extern "C" const char* hscmp_last_variant(hscmp_ctx* ctx) { return ctx ? ctx->variant.c_str() : ""; }
+
+// modeling.py:149-188 convolve1d on the GPU: full table out [Tout][K]
+template <typename R> static int run_convolve(hscmp_ctx* ctx, const void* x, int T, int same, void* out)
+{
+    const int K = ctx->K, W = ctx->W, F = ctx->F;
+    const int Tout = same ? T : T - W + 1;
+    if (Tout <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_convolve1d: T=%d shorter than the filters (W=%d)", T, W);
+    R* dx = nullptr; R* dout = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&dx, (size_t)T * F * sizeof(R)));
+    hipError_t e = hipMalloc((void**)&dout, (size_t)Tout * K * sizeof(R));
+    if (e != hipSuccess) { (void)hipFree(dx); return fail(ctx, HSCMP_ERR_ALLOC, "hscmp_convolve1d: %s", hipGetErrorString(e)); }
+    int rc = HSCMP_OK;
+    do {
+        if ((e = hipMemcpyAsync(dx, x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        DevParams P{};
+        P.B = 1; P.T = T; P.K = K; P.W = W; P.F = F; P.off = (W - 1) / 2;
+        State<R> S{};
+        S.D = (const R*)ctx->d_D; S.weights = nullptr;
+        dim3 grid((Tout + kThreads - 1) / kThreads, 1);
+        hipLaunchKernelGGL((corr_init_generic_kernel<R, true>), grid, dim3(kThreads), 0, ctx->stream, P, S, (const R*)dx,
+                           same ? P.off : 0, Tout, dout);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out, dout, (size_t)Tout * K * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_convolve1d: %s", hipGetErrorString(e));
+    (void)hipFree(dx); (void)hipFree(dout);
+    return rc;
+}
+
+extern "C" int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, void* out)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_convolve1d: ctx is NULL");
+    if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_convolve1d: no dictionary set");
+    if (!x || !out || T <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_convolve1d: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ctx->dtype == HSCMP_F32 ? run_convolve<float>(ctx, x, T, same, out) : run_convolve<double>(ctx, x, T, same, out);
+}

@@ -1,0 +1,143 @@
+// hscmp_device.h -- device-side building blocks shared by every kernel variant of the engine.
+//
+// Table-free formulation: the reference keeps the whole inner-product table
+// ip[T,K] (hsc/modeling.py:1077) and re-scans it for every selection (:967).  The engine keeps,
+// per position t, only the entry that can win the arg-max: (best_c[t], best_k[t]) = the
+// coefficient and atom index of max_k |ip[t,k]*w_k| (first k on ties), plus per-segment maxima
+// of those.  Every local update replaces whole rows of ip (:1049), so recomputing the 2W-1
+// touched rows and their per-position best is observably identical to the reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hscmp {
+
+constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxSeg = 1024;   // segment maxima kept in LDS per signal
+
+// Kernel parameters (by value).  Per-signal arrays are [B][...] with the strides below.
+struct DevParams {
+    int B, T, K, W, F;
+    int off;            // (W-1)/2: lead of the centred window (modeling.py:159-164, utils.py:84-99)
+    int seg, nseg;      // segment size (power of two >= 64) and count, nseg <= kMaxSeg
+    // selection (modeling.py:899-982)
+    int blocked;        // 0: single arg-max; 1: blocked
+    int bs, nbk;        // block size (even) and base block count ceil(T/bs)
+    int maxsel;         // capacity of the per-round selection list
+    // stop rules (modeling.py:1125-1158)
+    int l0;             // nbNonzeroCoefs or -1
+    int has_snr, has_scale, has_thres;
+    double snr_ratio;   // 10^(toleranceSnr/10): snr >= tol <=> Esig/Eres >= snr_ratio
+    double tol_scale;
+    double thres;       // nullCoeffThres
+    double eps;
+    int cap;            // max events per signal
+    int max_rounds;     // <= 0: until converged
+};
+
+enum { ST_NNZ = 0, ST_DUP = 1, ST_ROUNDS = 2, ST_STOP = 3, ST_ITERS = 4, ST_EVENTS = 5, ST_SLOTS = 6,
+       ST_OFFSET = 7, ST_COUNT = 8 };
+enum { STOP_RUNNING = 0, STOP_ENERGY_EPS = 1, STOP_NNZ = 2, STOP_SNR = 3, STOP_SCALE = 4, STOP_EMPTY = 5,
+       STOP_CALLBACK = 6, STOP_CAPACITY = 7 };
+
+template <typename R> struct State {
+    const R* D;         // [K][W][F]
+    const R* weights;   // [K] or nullptr
+    R* residual;        // [B][T*F]
+    R* best_c;          // [B][T]
+    int* best_k;        // [B][T]
+    int* ev_t; int* ev_k; R* ev_c;            // [B][cap]
+    int* slot_t; int* slot_k; double* slot_a; // [B][cap]
+    int* sel_t; int* sel_k; R* sel_c;         // [B][2*maxsel]  (two halves: raw / ordered)
+    int* stats;         // [B][ST_COUNT]
+    R* energy;          // [B][2]: signal, residual
+};
+
+__device__ __forceinline__ float rabs(float v) { return fabsf(v); }
+__device__ __forceinline__ double rabs(double v) { return fabs(v); }
+__device__ __forceinline__ float rfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double rfma(double a, double b, double c) { return fma(a, b, c); }
+
+// |c * w_k| exactly as modeling.py:906 then np.abs (one rounded product), or |c| without weights
+template <typename R> __device__ __forceinline__ R score_of(R c, int k, const R* w)
+{
+    if (w) { R s = c * w[k]; return rabs(s); }
+    return rabs(c);
+}
+
+// (score, index) candidate; larger score wins, then the smaller index (C-order arg-max, :967)
+template <typename R> struct Cand { R s; int i; };
+template <typename R> __device__ __forceinline__ bool better(const Cand<R>& a, const Cand<R>& b)
+{
+    return a.s > b.s || (a.s == b.s && a.i < b.i);
+}
+template <typename R> __device__ __forceinline__ Cand<R> wave_argmax(Cand<R> c)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Cand<R> o;
+        o.s = __shfl_xor(c.s, m);
+        o.i = __shfl_xor(c.i, m);
+        if (better(o, c)) c = o;
+    }
+    return c;
+}
+
+template <typename R> __device__ __forceinline__ R wave_max(R v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { R o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+
+// Pinned summation tree (DESIGN.md "Numerics", oracle hsco_energy_*): the caller has formed the
+// 256 strided partials p[tid]; halving tree inside each wave, then (P0+P1)+(P2+P3).
+// Returns the total in thread 0 (other threads: unspecified).  `scratch` holds >= 2*kWaves R's.
+template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        R oa = __shfl_down(a, m);
+        R ob = __shfl_down(b, m);
+        a = a + oa;
+        b = b + ob;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch[wv] = a; scratch[kWaves + wv] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        R a01 = scratch[0] + scratch[1];
+        R a23 = scratch[2] + scratch[3];
+        a = a01 + a23;
+        R b01 = scratch[kWaves + 0] + scratch[kWaves + 1];
+        R b23 = scratch[kWaves + 2] + scratch[kWaves + 3];
+        b = b01 + b23;
+    }
+}
+
+// utils.py:76-161: clipped support [s,e) of a width-W element centred at t, element offset es
+__device__ __forceinline__ int centered_span(int T, int W, int t, int& s, int& e, int& es)
+{
+    const int lo = t - (W - 1) / 2;
+    const int hi = t + W / 2 + 1;
+    s = lo < 0 ? 0 : lo;
+    e = hi > T ? T : hi;
+    es = s - lo;
+    return e - s;
+}
+
+// np.pad(mode='reflect') of the slice [sidx, sidx+n) evaluated at global index g (modeling.py:1046)
+__device__ __forceinline__ int reflect_index(int g, int sidx, int n)
+{
+    if (n == 1) return sidx;
+    const int period = 2 * (n - 1);
+    int m = (g - sidx) % period;
+    if (m < 0) m += period;
+    if (m >= n) m = period - m;
+    return sidx + m;
+}
+
+}  // namespace hscmp

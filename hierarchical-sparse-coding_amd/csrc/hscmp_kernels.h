@@ -1,0 +1,505 @@
+// hscmp_kernels.h -- the kernels of the engine, generic over element type and shape.
+//
+//   prepare_kernel      residual = copy(x), signal energy            (modeling.py:1070-1072)
+//   corr_init_kernel    initial zero-padded 'same' correlation       (modeling.py:1077, 149-188)
+//                       reduced on the fly to the per-position best (or the full table for
+//                       the convolve1d entry point)
+//   iterate_kernel      the greedy loop                              (modeling.py:1086-1163)
+//                       one persistent workgroup per signal: select (single or blocked arg-max,
+//                       :899-982) -> coefficient bookkeeping (:1106-1114) -> residual subtract
+//                       with energy tracking (:996-1016) -> local re-correlation of the 2W-1
+//                       touched rows (:1018-1051) -> stop rules (:1125-1158), no host round trip.
+//
+// The re-correlation of the touched rows is a policy (`Recorr`): GenericRecorr below is the
+// any-shape / any-dtype VALU version; hscmp_mfma.h provides the MFMA (matrix-core) one.
+#pragma once
+
+#include "hscmp_device.h"
+
+#include <limits.h>
+
+namespace hscmp {
+
+// ------------------------------------------------------------------------------------------------
+// prepare: residual <- x, energies, counters          grid = B, block = kThreads
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(kThreads) void prepare_kernel(DevParams P, State<R> S, const R* __restrict__ x)
+{
+    __shared__ R red[2 * kWaves];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t n = (int64_t)P.T * P.F;
+    const R* xs = x + (int64_t)b * n;
+    R* r = S.residual + (int64_t)b * n;
+    R p = (R)0, q = (R)0;
+    for (int64_t i = tid; i < n; i += kThreads) {   // strided partials, sequential in i (pinned order)
+        const R v = xs[i];
+        r[i] = v;
+        const R sq = v * v;
+        p = p + sq;
+    }
+    pinned_tree2(p, q, red);
+    if (tid == 0) {
+        S.energy[2 * b + 0] = p;
+        S.energy[2 * b + 1] = p;
+        int* st = S.stats + (int64_t)b * ST_COUNT;
+        for (int i = 0; i < ST_COUNT; ++i) st[i] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic initial correlation: one thread per output position, all atoms, pinned fma chain
+//   grid = (ceil(Tout/kThreads), B), block = kThreads
+//   TABLE = false: write per-position best (best_c, best_k);  TABLE = true: write out[Tout][K]
+// ------------------------------------------------------------------------------------------------
+template <typename R, bool TABLE>
+__global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P, State<R> S, const R* __restrict__ src,
+                                                                      int lead, int Tout, R* __restrict__ table)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= Tout) return;
+    const int T = P.T, K = P.K, W = P.W, F = P.F;
+    const R* x = src + (int64_t)b * T * F;
+    const R* __restrict__ D = S.D;
+    R bs = (R)-1, bc = (R)0;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+        R acc = (R)0;
+        const R* dk = D + (int64_t)k * W * F;
+        for (int f = 0; f < F; ++f)
+            for (int w = 0; w < W; ++w) {
+                const int g = t - lead + w;
+                const R xv = (g >= 0 && g < T) ? x[(int64_t)g * F + f] : (R)0;
+                acc = rfma(xv, dk[w * F + f], acc);
+            }
+        if (TABLE) {
+            table[((int64_t)b * Tout + t) * K + k] = acc;
+        } else {
+            const R sc = score_of(acc, k, S.weights);
+            if (sc > bs) { bs = sc; bc = acc; bk = k; }
+        }
+    }
+    if (!TABLE) {
+        S.best_c[(int64_t)b * T + t] = bc;
+        S.best_k[(int64_t)b * T + t] = bk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared state of the greedy loop
+// ------------------------------------------------------------------------------------------------
+template <typename R> struct IterShared {
+    R seg_score[kMaxSeg];
+    R seg_c[kMaxSeg];
+    int seg_t[kMaxSeg];
+    int seg_k[kMaxSeg];
+    R rseg[kMaxSeg];          // max |residual| per segment (toleranceResidualScale only)
+    R part_s[kThreads];
+    R part_c[kThreads];
+    int part_k[kThreads];
+    R red[2 * kWaves];
+    Cand<R> cred[kWaves];
+    int wtot[kWaves];
+    // control block (written by thread 0, read by all after a barrier)
+    int nsel, converged, stop, found, skip;
+    int nnz, ndup, rounds, iters, nev, nslots, offset;
+    int atom_t, atom_k;
+    R atom_c;
+    R e_sig, e_res;
+};
+
+template <typename R> struct Sig {   // per-signal views
+    R* r; R* bc; int* bk;
+    int* ev_t; int* ev_k; R* ev_c;
+    int* slot_t; int* slot_k; double* slot_a;
+    int* sel_t; int* sel_k; R* sel_c;
+};
+
+// arg-max of the per-position best over positions [t0,t1) by one wave; result in all lanes
+template <typename R>
+__device__ __forceinline__ Cand<R> wave_range_argmax(const Sig<R>& G, const R* w, int t0, int t1, int lane)
+{
+    Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+    for (int t = t0 + lane; t < t1; t += 64) {
+        const R s = score_of(G.bc[t], G.bk[t], w);
+        if (s > best.s) { best.s = s; best.i = t; }
+    }
+    return wave_argmax(best);
+}
+
+template <typename R>
+__device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G, const R* w, IterShared<R>& sh, int sg, int lane)
+{
+    const int t0 = sg * P.seg;
+    const int t1 = min(P.T, t0 + P.seg);
+    Cand<R> win = wave_range_argmax(G, w, t0, t1, lane);
+    if (lane == 0) {
+        if (win.i == INT_MAX) { win.i = t0; win.s = (R)0; }
+        sh.seg_score[sg] = win.s;
+        sh.seg_t[sg] = win.i;
+        sh.seg_c[sg] = G.bc[win.i];
+        sh.seg_k[sg] = G.bk[win.i];
+    }
+}
+
+template <typename R>
+__device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& G, IterShared<R>& sh, int sg, int lane)
+{
+    const int64_t i0 = (int64_t)sg * P.seg * P.F;
+    const int64_t i1 = (int64_t)min(P.T, (sg + 1) * P.seg) * P.F;
+    R m = (R)0;
+    for (int64_t i = i0 + lane; i < i1; i += 64) { const R a = rabs(G.r[i]); m = a > m ? a : m; }
+    m = wave_max(m);
+    if (lane == 0) sh.rseg[sg] = m;
+}
+
+// block-wide stable compaction of list entries [0,n) with predicate pred(i): src -> dst; returns count
+template <typename R, typename Pred>
+__device__ __forceinline__ int block_compact(int n, Pred pred, const int* st, const int* sk, const R* sc,
+                                              int* dt, int* dk, R* dc, IterShared<R>& sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int running = 0;
+    for (int base = 0; base < n; base += kThreads) {
+        const int i = base + tid;
+        const int f = (i < n) ? (pred(i) ? 1 : 0) : 0;
+        const unsigned long long mask = __ballot(f);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) sh.wtot[wv] = __popcll(mask);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < kWaves; ++q) { const int c = sh.wtot[q]; if (q < wv) before += c; total += c; }
+        if (f) {
+            const int o = running + before + prefix;
+            dt[o] = st[i]; dk[o] = sk[i]; dc[o] = sc[i];
+        }
+        running += total;
+    }
+    __syncthreads();
+    return running;
+}
+
+// energy of the clipped window centred at t, pinned order; result valid in thread 0
+template <typename R>
+__device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R>& G, IterShared<R>& sh, int t, int& len)
+{
+    int s, e, es;
+    len = centered_span(P.T, P.W, t, s, e, es);
+    R p = (R)0, q = (R)0;
+    if (len > 0) {
+        const int n = len * P.F;
+        const R* v = G.r + (int64_t)s * P.F;
+        for (int i = threadIdx.x; i < n; i += kThreads) { const R sq = v[i] * v[i]; p = p + sq; }
+    }
+    pinned_tree2(p, q, sh.red);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GenericRecorr: re-correlate rows p-(W-1)..p+(W-1) against the reflect-padded residual span
+// (modeling.py:1018-1051), reduce each row to its per-position best, write best_c/best_k.
+// Threads = (row, atom group); the per-atom fma chain order is the pinned one (f outer, w inner).
+// ------------------------------------------------------------------------------------------------
+template <typename R> struct GenericRecorr {
+    static constexpr size_t dynamic_lds_bytes(const DevParams&) { return 0; }
+    static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G,
+                                               IterShared<R>& sh, int p)
+    {
+        const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x;
+        const int nrows = 2 * W - 1;
+        const int tstart = p - P.off - (W - 1);            // :1028-1033
+        const int tend = p + W / 2 + (W - 1);              // :1038
+        const int sidx = tstart < 0 ? 0 : tstart;          // :1034
+        const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
+        const int nslice = eidx - sidx + 1;
+        const bool interior = (tstart >= 0) && (tend <= T - 1);
+        const int rpp = nrows < kThreads ? nrows : kThreads;
+        int ngrp = kThreads / rpp;
+        if (ngrp > K) ngrp = K;
+        if (ngrp < 1) ngrp = 1;
+        const R* __restrict__ D = S.D;
+        for (int base = 0; base < nrows; base += rpp) {
+            const int j = base + tid % rpp;
+            const int g = tid / rpp;
+            const int t = p - (W - 1) + j;
+            const bool rowok = (j < nrows) && (t >= 0) && (t < T);   // overlapReplace clipping, utils.py:133-161
+            R bs = (R)-1, bc = (R)0;
+            int bk = 0;
+            if (rowok && g < ngrp) {
+                const int k0 = (int)(((int64_t)K * g) / ngrp), k1 = (int)(((int64_t)K * (g + 1)) / ngrp);
+                for (int k = k0; k < k1; ++k) {
+                    const R* dk = D + (int64_t)k * W * F;
+                    R acc = (R)0;
+                    for (int f = 0; f < F; ++f)
+                        for (int w = 0; w < W; ++w) {
+                            int gi = t - P.off + w;
+                            if (!interior) gi = reflect_index(gi, sidx, nslice);   // np.pad 'reflect', :1046
+                            acc = rfma(G.r[(int64_t)gi * F + f], dk[w * F + f], acc);
+                        }
+                    const R sc = score_of(acc, k, S.weights);
+                    if (sc > bs) { bs = sc; bc = acc; bk = k; }
+                }
+            }
+            sh.part_s[tid] = bs; sh.part_c[tid] = bc; sh.part_k[tid] = bk;
+            __syncthreads();
+            if (g == 0 && rowok) {
+                for (int q = 1; q < ngrp; ++q) {       // ascending atom groups, strict > keeps the lowest k
+                    const int o = q * rpp + tid;
+                    if (sh.part_s[o] > bs) { bs = sh.part_s[o]; bc = sh.part_c[o]; bk = sh.part_k[o]; }
+                }
+                G.bc[t] = bc;
+                G.bk[t] = bk;
+            }
+            __syncthreads();
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the greedy loop            grid = B, block = kThreads, one persistent workgroup per signal
+// ------------------------------------------------------------------------------------------------
+template <typename R, typename Recorr>
+__global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R> S)
+{
+    __shared__ IterShared<R> sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int* stats = S.stats + (int64_t)b * ST_COUNT;
+    if (stats[ST_STOP] != STOP_RUNNING) return;          // converged in an earlier launch
+
+    const int T = P.T, W = P.W, F = P.F;
+    Sig<R> G;
+    G.r = S.residual + (int64_t)b * T * F;
+    G.bc = S.best_c + (int64_t)b * T;
+    G.bk = S.best_k + (int64_t)b * T;
+    G.ev_t = S.ev_t + (int64_t)b * P.cap; G.ev_k = S.ev_k + (int64_t)b * P.cap; G.ev_c = S.ev_c + (int64_t)b * P.cap;
+    G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
+    G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
+    const R* __restrict__ wts = S.weights;
+
+    // ---- prologue: segment maxima of the per-position best (and of |residual|)
+    for (int sg = wv; sg < P.nseg; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
+    if (P.has_scale) for (int sg = wv; sg < P.nseg; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
+    if (tid == 0) {
+        sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
+        sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
+        sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1;
+        sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
+    }
+    __syncthreads();
+
+    int* raw_t = G.sel_t; int* raw_k = G.sel_k; R* raw_c = G.sel_c;                       // first half
+    int* ord_t = G.sel_t + P.maxsel; int* ord_k = G.sel_k + P.maxsel; R* ord_c = G.sel_c + P.maxsel; // second half
+    const double thres = P.thres;
+    const bool has_thres = P.has_thres != 0;
+
+    for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
+        int nsel;
+        // =========================== select (modeling.py:899-982) ===========================
+        if (!P.blocked) {
+            // :965-975 flat arg-max == arg-max over the segment maxima (ties: lowest t, then k)
+            Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
+            for (int i = tid; i < P.nseg; i += kThreads) {
+                Cand<R> o; o.s = sh.seg_score[i]; o.i = i;
+                if (better(o, c)) c = o;
+            }
+            c = wave_argmax(c);
+            if (lane == 0) sh.cred[wv] = c;
+            __syncthreads();
+            if (tid == 0) {
+                Cand<R> m = sh.cred[0];
+                for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
+                const int sg = m.i;
+                const R cc = sh.seg_c[sg];
+                sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
+                sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
+            }
+            __syncthreads();
+            nsel = sh.nsel;
+        } else {
+            // :908-937 one arg-max per block of bs samples (half-block shifted when offset is set)
+            const int off = sh.offset;
+            const int nb = P.nbk + (off ? 1 : 0);
+            const int pad0 = off ? P.bs / 2 : 0;
+            for (int j = wv; j < nb; j += kWaves) {
+                const int w0 = j * P.bs - pad0;
+                const int lo = w0 < 0 ? 0 : w0;
+                const int hi = min(T, w0 + P.bs);
+                Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
+                if (lo < hi) win = wave_range_argmax(G, wts, lo, hi, lane);
+                if (lane == 0) {
+                    bool valid = (lo < hi) && win.i != INT_MAX;                  // :940-942 range test
+                    if (valid && win.s == (R)0 && w0 < 0) valid = false;         // arg-max on a leading padded row
+                    raw_t[j] = valid ? win.i : -1;
+                    raw_k[j] = valid ? G.bk[win.i] : 0;
+                    raw_c[j] = valid ? G.bc[win.i] : (R)0;
+                }
+            }
+            __syncthreads();
+            // :946-948 drop null coefficients (and invalid blocks): raw -> ord
+            int n = block_compact(nb, [&](int i) { return raw_t[i] >= 0 && (!has_thres || fabs((double)raw_c[i]) > thres); },
+                                  raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh);
+            // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
+            if (n > 1) {
+                int cnt = 0;
+                for (int i = 1 + tid; i < n; i += kThreads) cnt += (ord_t[i] - ord_t[i - 1] >= W) ? 1 : 0;
+                cnt = __syncthreads_count(cnt > 0);   // > 0 iff some gap qualifies
+                if (cnt > 0) {
+                    n = block_compact(n, [&](int i) { return i == 0 || (ord_t[i] - ord_t[i - 1] >= W); },
+                                      ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                } else {
+                    n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                }
+            } else {
+                n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+            }
+            // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals (rank sort)
+            for (int i = tid; i < n; i += kThreads) {
+                const R a = rabs(raw_c[i]);
+                int rank = 0;
+                for (int q = 0; q < n; ++q) {
+                    const R o = rabs(raw_c[q]);
+                    rank += (o > a || (o == a && q > i)) ? 1 : 0;
+                }
+                ord_t[rank] = raw_t[i]; ord_k[rank] = raw_k[i]; ord_c[rank] = raw_c[i];
+            }
+            __syncthreads();
+            // :1090-1099 weak-atom filter
+            if (P.has_snr && n > 1) {
+                const R tol_energy = sh.e_sig / (R)P.snr_ratio;
+                const double thr = (double)tol_energy / (double)((int64_t)T * F);
+                for (int i = 0; i < n; ++i) {
+                    int len;
+                    const R e = block_window_energy(P, G, sh, ord_t[i], len);
+                    if (tid == 0) {
+                        const R mean = e / (R)((int64_t)len * F);
+                        raw_t[i] = ((double)mean >= thr) ? 1 : 0;      // keep flag (raw half is free now)
+                    }
+                }
+                __syncthreads();
+                // keep flags live in raw_t; entry o <= i is only overwritten after flag i was read
+                // (block_compact evaluates a whole 256-chunk of predicates before it writes)
+                n = block_compact(n, [&](int i) { return raw_t[i] != 0; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                n = block_compact(n, [&](int) { return true; }, raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh);
+            }
+            if (tid == 0) sh.nsel = n;
+            __syncthreads();
+            nsel = sh.nsel;
+        }
+
+        // =========================== apply the selected atoms (:1101-1142) ===========================
+        for (int ai = 0; ai < nsel; ++ai) {
+            int p, k; R c;
+            if (!P.blocked) { p = sh.atom_t; k = sh.atom_k; c = sh.atom_c; }
+            else { p = ord_t[ai]; k = ord_k[ai]; c = ord_c[ai]; }
+
+            // ---- :1106-1114 duplicate / nnz bookkeeping, coefficient accumulation, event append
+            if (tid == 0) sh.found = -1;
+            __syncthreads();
+            const int nslots = sh.nslots;
+            for (int i = tid; i < nslots; i += kThreads)
+                if (G.slot_t[i] == p && G.slot_k[i] == k) sh.found = i;          // at most one match
+            __syncthreads();
+            if (tid == 0) {
+                if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
+                else {
+                    int si = sh.found;
+                    if (si >= 0 && fabs(G.slot_a[si]) > 0.0) sh.ndup += 1;
+                    else if (rabs(c) > (R)0) sh.nnz += 1;
+                    if (si < 0) { si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; G.slot_a[si] = 0.0; }
+                    G.slot_a[si] += (double)c;
+                    const int e = sh.nev++;
+                    G.ev_t[e] = p; G.ev_k[e] = k; G.ev_c[e] = c;
+                }
+            }
+            __syncthreads();
+            if (sh.skip) break;
+
+            // ---- :1117, :996-1016 residual subtract with local energy before / after
+            int s, e, es;
+            const int len = centered_span(T, W, p, s, e, es);
+            R pb = (R)0, pa = (R)0;
+            {
+                const int n = len * F;
+                const R nc = -c;
+                const R* dk = S.D + ((int64_t)k * W + es) * F;
+                R* rv = G.r + (int64_t)s * F;
+                for (int i = tid; i < n; i += kThreads) {
+                    const R v = rv[i];
+                    const R sq = v * v;
+                    pb = pb + sq;
+                    const R prod = nc * dk[i];       // -c*D[k] rounded, then += (utils.py:120,129)
+                    const R vn = v + prod;
+                    rv[i] = vn;
+                    const R sq2 = vn * vn;
+                    pa = pa + sq2;
+                }
+            }
+            pinned_tree2(pb, pa, sh.red);
+            if (tid == 0) {
+                const R loss = pb - pa;              // :1005
+                sh.e_res = sh.e_res - loss;          // :1014
+            }
+            __syncthreads();                         // residual writes visible to the whole workgroup
+            if (P.has_scale) {
+                const int sg0 = s / P.seg, sg1 = (e - 1) / P.seg;
+                for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
+            }
+
+            // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
+            Recorr::run(P, S, G, sh, p);
+            __syncthreads();
+
+            // ---- refresh the maxima of the touched segments
+            {
+                const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
+                const int sg0 = lo / P.seg, sg1 = hi / P.seg;
+                for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
+            }
+
+            // ---- :1122-1142 fast stop rules
+            if (tid == 0) {
+                sh.iters += 1;
+                if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
+                else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
+                else if (P.has_snr) {
+                    const R q = sh.e_sig / sh.e_res;
+                    if ((double)q >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
+                }
+            }
+            __syncthreads();
+            if (sh.converged) break;
+        }
+
+        // =========================== slow stop rules (:1145-1163) ===========================
+        if (P.has_scale) {
+            R m = (R)0;
+            for (int i = tid; i < P.nseg; i += kThreads) { const R a = sh.rseg[i]; m = a > m ? a : m; }
+            m = wave_max(m);
+            __syncthreads();
+            if (lane == 0) sh.red[wv] = m;
+            __syncthreads();
+            if (tid == 0) {
+                for (int q = 1; q < kWaves; ++q) m = sh.red[q] > m ? sh.red[q] : m;
+                if ((double)m <= P.tol_scale) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_SCALE; }
+            }
+        }
+        if (tid == 0) {
+            if (nsel == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
+            sh.rounds += 1;
+            sh.offset = !sh.offset;
+        }
+        __syncthreads();
+        if (sh.converged) break;
+    }
+
+    if (tid == 0) {
+        stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;
+        stats[ST_ITERS] = sh.iters; stats[ST_EVENTS] = sh.nev; stats[ST_SLOTS] = sh.nslots; stats[ST_OFFSET] = sh.offset;
+        S.energy[2 * b + 1] = sh.e_res;
+    }
+}
+
+}  // namespace hscmp

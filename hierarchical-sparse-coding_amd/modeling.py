@@ -1,0 +1,261 @@
+"""Drop-in for the matching-pursuit path of the reference's `hsc.modeling` (same class / method
+names, argument meaning, return types and error behaviour), running on MI355X through
+libhscmp.so (include/hscmp.h).
+
+Reference surface reproduced here (hsc/modeling.py):
+  convolve1d (:149-188), reconstructSignal (:226-263), Atom (:840-864),
+  ConvolutionalMatchingPursuit.computeCoefficients (:1053-1186),
+  ConvolutionalSparseCoder (:1656-1669).
+The hierarchical encoder lives in hsc_amd.hierarchical and is re-exported below.
+
+Added (the reference has no batch dimension): ConvolutionalMatchingPursuit.computeCoefficientsBatch.
+
+There is no CPU implementation of the greedy loop in this package: without libhscmp.so / an
+MI355X the calls raise hsc_amd._native.HscmpError.
+"""
+import logging
+
+import numpy as np
+import scipy.sparse
+
+from . import _native
+from .utils import overlapAdd
+
+logger = logging.getLogger(__name__)
+
+
+def _compute_dtype(*dtypes):
+    dt = np.result_type(*dtypes)
+    if dt == np.float32:
+        return np.dtype(np.float32)
+    return np.dtype(np.float64)     # float64, and everything else (ints, float16, ...) promotes to it
+
+
+def convolve1d(sequence, filters, padding='valid', device=0):
+    """hsc/modeling.py:149-188 -- cross-correlation (no flip) of `sequence` [T] or [T,F] with
+    `filters` [K,W] or [K,W,F]; 'same' is zero padded with (W/2-1, W/2) for even W and
+    (W//2, W//2) for odd W.  Returns [Tout, K]."""
+    if padding not in ('valid', 'same'):
+        raise Exception('Padding not supported: %s' % (padding))
+    seq2 = np.atleast_2d(sequence).reshape((sequence.shape[0], -1))
+    nbFeatures = 1 if filters.ndim == 2 else filters.shape[-1]
+    assert nbFeatures == seq2.shape[-1]
+    dt = _compute_dtype(seq2.dtype, filters.dtype)
+    eng = _native.default_engine(device)
+    eng.set_dictionary(np.asarray(filters, dtype=dt))
+    return eng.convolve1d(np.asarray(seq2, dtype=dt), same=(padding == 'same'))
+
+
+def convolve1d_batch(sequences, filters, padding='valid', device=0):
+    """hsc/modeling.py:190-224 -- convolve1d over a leading batch axis: [B,T(,F)] -> [B,Tout,K]."""
+    if padding not in ('valid', 'same'):
+        raise Exception('Padding not supported: %s' % (padding))
+    seqs = np.atleast_3d(sequences).reshape((sequences.shape[0], sequences.shape[1], -1))
+    nbFeatures = 1 if filters.ndim == 2 else filters.shape[-1]
+    assert nbFeatures == seqs.shape[-1]
+    dt = _compute_dtype(seqs.dtype, filters.dtype)
+    eng = _native.default_engine(device)
+    eng.set_dictionary(np.asarray(filters, dtype=dt))
+    return np.stack([eng.convolve1d(np.asarray(s, dtype=dt), same=(padding == 'same')) for s in seqs], axis=0)
+
+
+def reconstructSignal(coefficients, D):
+    """hsc/modeling.py:226-263 -- synthesis: sum of c * D[k] centred at t over the non-zero
+    coefficients [T,K] (sparse or dense).  Host-side overlap-add of the (few) events."""
+    assert coefficients.ndim == 1 or coefficients.ndim == 2
+    assert D.ndim == 2 or D.ndim == 3
+    squeezeOutput = D.ndim == 2
+    D3 = D[:, :, np.newaxis] if D.ndim == 2 else D
+    signal = np.zeros((coefficients.shape[0], D3.shape[-1]), dtype=coefficients.dtype)
+    if scipy.sparse.issparse(coefficients):
+        cx = coefficients.tocoo()
+        rows, cols, data = cx.row, cx.col, cx.data
+    else:
+        dense = np.asarray(coefficients)
+        rows, cols = np.nonzero(dense)
+        data = dense[rows, cols]
+    for t, k, c in zip(rows, cols, data):
+        if c != 0.0:
+            overlapAdd(signal, c * D3[k], int(t), copy=False)
+    if squeezeOutput:
+        signal = np.squeeze(signal, axis=1)
+    return signal
+
+
+class Atom(object):
+    """hsc/modeling.py:840-864"""
+
+    def __init__(self, position, index, coefficient, length):
+        self.__dict__.update(position=position, index=index, coefficient=coefficient, length=length)
+
+    def getPositionSpanIndices(self, sequenceLength=None):
+        startIdx = self.position - (self.length - 1) // 2
+        endIdx = self.position + self.length // 2
+        if sequenceLength is not None:
+            startIdx = max(startIdx, 0)
+            endIdx = min(endIdx, sequenceLength - 1)
+        return startIdx, endIdx
+
+    def __str__(self):
+        return 'Atom no.%d of length %d at position %d, c = %4.10f' % (self.index, self.length, self.position, self.coefficient)
+
+    __repr__ = __str__
+
+
+class SparseApproximator(object):
+    """hsc/modeling.py:657-660 -- the plugin seam: anything with computeCoefficients(X, D, **kw)."""
+
+    def computeCoefficients(self, X, D):
+        raise NotImplementedError()
+
+
+def _slots_to_csc(slot_t, slot_k, slot_a, n, shape, minCoefficients):
+    """hsc/modeling.py:1171-1181: clip |c| < minCoefficients, CSC, eliminate zeros."""
+    t, k, a = slot_t[:n], slot_k[:n], slot_a[:n]
+    keep = a != 0.0
+    if minCoefficients is not None:
+        keep &= np.abs(a) >= minCoefficients
+    m = scipy.sparse.csc_matrix((a[keep].astype(np.float64), (t[keep].astype(np.int64), k[keep].astype(np.int64))), shape=shape)
+    m.sort_indices()
+    return m
+
+
+class BatchResult(object):
+    """Per-signal outputs of computeCoefficientsBatch (everything the reference returns, plus the
+    ordered selection trace the reference only logs)."""
+
+    def __init__(self, coefficients, residuals, events, stats, energies, variant, kernel_ms):
+        self.coefficients = coefficients      # list of csc_matrix float64 [T,K]
+        self.residuals = residuals            # [B,T] or [B,T,F]
+        self.events = events                  # list of (t int32[n], k int32[n], c dtype[n]) in selection order
+        self.stats = stats                    # int32 [B,8], hscmp.h HSCMP_STAT_*
+        self.energies = energies              # float64 [B,2]: signal, tracked residual
+        self.variant = variant
+        self.kernel_ms = kernel_ms
+
+    def stop_reasons(self):
+        return [_native.STOP_NAMES.get(int(s), int(s)) for s in self.stats[:, _native.STAT_STOP]]
+
+
+class ConvolutionalMatchingPursuit(SparseApproximator):
+    """hsc/modeling.py:866-1186, greedy convolutional matching pursuit, on the GPU."""
+
+    def __init__(self, verbose=False, device=0):
+        self.verbose = verbose
+        self.device = device
+        self.fig = None
+        self.lastResult = None
+
+    # ---------------------------------------------------------------------------------------
+    def computeCoefficientsBatch(self, sequences, D, nbNonzeroCoefs=None, toleranceResidualScale=None,
+                                 toleranceSnr=None, nbBlocks=1, minCoefficients=1e-16, weights=None,
+                                 stopCondition=None, maxEvents=None):
+        """Batch form of computeCoefficients: `sequences` is [B,T] (D [K,W]) or [B,T,F] (D [K,W,F]).
+        The B signals are independent (no cross-signal term in modeling.py:1053-1186) and are
+        encoded concurrently, one persistent workgroup each.  Returns a BatchResult."""
+        assert sequences.ndim == 2 or sequences.ndim == 3
+        assert D.ndim == 2 or D.ndim == 3
+        eps = float(np.finfo(D.dtype).eps) if np.issubdtype(D.dtype, np.floating) else float(np.finfo(np.float64).eps)
+        dt = _compute_dtype(sequences.dtype, D.dtype)
+        B, T = sequences.shape[0], sequences.shape[1]
+        x = np.ascontiguousarray(sequences.reshape((B, T, -1)), dtype=dt)
+        D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt)
+        K, W, F = D3.shape
+        assert F == x.shape[2]
+        if weights is not None:
+            assert len(weights) == K
+        eng = _native.default_engine(self.device)
+        eng.set_dictionary(D3, None if weights is None else np.asarray(weights, dtype=dt))
+
+        if maxEvents is None:
+            maxEvents = 2 * int(nbNonzeroCoefs) + 64 if nbNonzeroCoefs is not None else 4096
+        per_round = stopCondition is not None
+        while True:
+            params = _native.make_params(nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
+                                         minCoefficients, eps, maxEvents, 1 if per_round else 0)
+            eng.encode_batch(x, params)
+            if per_round:
+                self._run_with_callback(eng, sequences, D, K, T, minCoefficients, stopCondition)
+            stats = eng.fetch_stats()
+            if np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
+                maxEvents *= 4          # event list was too short for this stop rule: start over, larger
+                continue
+            break
+
+        ev_t, ev_k, ev_c = eng.fetch_events()
+        st, sk, sa = eng.fetch_slots()
+        residuals = eng.fetch_residual()
+        energies = eng.fetch_energies()
+        coefficients, events = [], []
+        for b in range(B):
+            ne, ns = int(stats[b, _native.STAT_EVENTS]), int(stats[b, _native.STAT_SLOTS])
+            coefficients.append(_slots_to_csc(st[b], sk[b], sa[b], ns, (T, K), minCoefficients))
+            events.append((ev_t[b, :ne].copy(), ev_k[b, :ne].copy(), ev_c[b, :ne].copy()))
+        if sequences.ndim == 2 or D.ndim == 2:
+            residuals = np.squeeze(residuals, axis=2)                      # modeling.py:1183-1184
+        if residuals.dtype != sequences.dtype and np.issubdtype(sequences.dtype, np.floating):
+            residuals = residuals.astype(sequences.dtype)
+        res = BatchResult(coefficients, residuals, events, stats, energies, eng.last_variant(), eng.last_kernel_ms())
+        self.lastResult = res
+        if self.verbose:
+            for b in range(B):
+                for t, k, c in zip(*events[b]):
+                    logger.info('Matching pursuit: raw event is (t = %d, f = %d, c = %f)' % (t, k, c))
+        for b in range(B):
+            logger.debug('signal %d: %d selections in %d rounds, nnz %d, duplicates %d, stop: %s' % (
+                b, stats[b, _native.STAT_ITERATIONS], stats[b, _native.STAT_ROUNDS], stats[b, _native.STAT_NNZ],
+                stats[b, _native.STAT_DUPLICATES], _native.STOP_NAMES.get(int(stats[b, _native.STAT_STOP]))))
+        return res
+
+    def _run_with_callback(self, eng, sequences, D, K, T, minCoefficients, stopCondition):
+        """modeling.py:1155-1158: stopCondition(sequence, residual, coefficients) after every
+        selection round.  One GPU launch per round; the callback sees host copies."""
+        while True:
+            stats = eng.fetch_stats()
+            running = np.where(stats[:, _native.STAT_STOP] == _native.STOP_RUNNING)[0]
+            if running.size == 0:
+                return
+            st, sk, sa = eng.fetch_slots()
+            residuals = eng.fetch_residual()
+            for b in running:
+                ns = int(stats[b, _native.STAT_SLOTS])
+                coef = scipy.sparse.lil_matrix((T, K))
+                if ns > 0:
+                    coef[st[b, :ns], sk[b, :ns]] = sa[b, :ns]
+                seq = sequences[b].reshape((T, -1))                        # the reference passes [T,F] views
+                if stopCondition(seq, residuals[b], coef):
+                    logger.warning('Custom stop condition reached: considering convergence is achieved')
+                    eng.stop_signal(int(b))
+            eng.continue_rounds(1)
+
+    # ---------------------------------------------------------------------------------------
+    def computeCoefficients(self, sequence, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
+                            nbBlocks=1, minCoefficients=1e-16, weights=None, stopCondition=None):
+        """hsc/modeling.py:1053-1186.  Returns (scipy.sparse.csc_matrix float64 [T,K], residual
+        with the shape / dtype rules of :1183-1186)."""
+        assert sequence.ndim == 1 or sequence.ndim == 2
+        assert D.ndim == 2 or D.ndim == 3
+        sequence = np.asarray(sequence)
+        res = self.computeCoefficientsBatch(sequence[np.newaxis], D, nbNonzeroCoefs, toleranceResidualScale,
+                                            toleranceSnr, nbBlocks, minCoefficients, weights, stopCondition)
+        return res.coefficients[0], res.residuals[0]
+
+
+class ConvolutionalSparseCoder(object):
+    """hsc/modeling.py:1656-1669"""
+
+    def __init__(self, D, approximator):
+        assert D.ndim == 2 or D.ndim == 3
+        self.D = D
+        self.approximator = approximator
+
+    def encode(self, X, *args, **kwargs):
+        assert X.ndim == 1 or X.ndim == 2
+        return self.approximator.computeCoefficients(X, self.D, *args, **kwargs)
+
+    def encodeBatch(self, X, *args, **kwargs):
+        return self.approximator.computeCoefficientsBatch(X, self.D, *args, **kwargs)
+
+    def reconstruct(self, coefficients):
+        assert coefficients.ndim == 1 or coefficients.ndim == 2
+        return reconstructSignal(coefficients, self.D)

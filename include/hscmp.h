@@ -1,0 +1,159 @@
+/*
+ * hscmp.h -- C ABI of the MI355X-native convolutional matching-pursuit engine (libhscmp.so).
+ *
+ * The reference (sbrodeur/hierarchical-sparse-coding) is pure Python and has no FFI; its plugin
+ * seam for this path is the `SparseApproximator` duck type (hsc/modeling.py:657-660):
+ * `computeCoefficients(sequence, D, **kw) -> (coefficients, residual)`.  The entry points below
+ * are what a ctypes binding of that seam needs (INTEGRATION.md shows the stub); each one names
+ * the reference code it replaces.  Plain C types only: pointers, sizes, PODs.  No torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative hscmp_status otherwise; the message is
+ *     available from hscmp_last_error(ctx) (thread-local for ctx == NULL failures);
+ *   - the caller owns every buffer it passes; the library never keeps a caller pointer after
+ *     the call returns (device-pointer entry points: until the work queued on the context's
+ *     stream has completed -- hscmp_synchronize);
+ *   - a context is bound to one GPU and is not thread-safe; contexts on different GPUs (or
+ *     several on one GPU) may be used concurrently from different threads / processes;
+ *   - arrays are C-contiguous: signals [B][T][F], dictionary [K][W][F] (reference layout,
+ *     modeling.py:1059-1067), events [B][max_events].
+ */
+#ifndef HSCMP_H
+#define HSCMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSCMP_VERSION 100
+
+typedef struct hscmp_ctx hscmp_ctx;
+
+typedef enum hscmp_status {
+    HSCMP_OK = 0,
+    HSCMP_ERR_INVALID = -1,      /* bad argument */
+    HSCMP_ERR_HIP = -2,          /* HIP runtime error (message has the HIP string) */
+    HSCMP_ERR_NO_DEVICE = -3,    /* no gfx950 device / extension cannot run here */
+    HSCMP_ERR_STATE = -4,        /* call sequence error (no dictionary, no batch, ...) */
+    HSCMP_ERR_UNSUPPORTED = -5,  /* shape outside what the kernels are built for */
+    HSCMP_ERR_ALLOC = -6
+} hscmp_status;
+
+typedef enum hscmp_dtype { HSCMP_F32 = 0, HSCMP_F64 = 1 } hscmp_dtype;
+
+/* per-signal stop reason, in the order the reference tests them (modeling.py:1125-1158) */
+typedef enum hscmp_stop {
+    HSCMP_RUNNING = 0,             /* max_rounds reached, not converged: hscmp_continue() resumes */
+    HSCMP_STOP_ENERGY_EPS = 1,     /* modeling.py:1125-1130 */
+    HSCMP_STOP_NNZ = 2,            /* modeling.py:1135-1138 */
+    HSCMP_STOP_SNR = 3,            /* modeling.py:1139-1142 */
+    HSCMP_STOP_RESIDUAL_SCALE = 4, /* modeling.py:1145-1148 */
+    HSCMP_STOP_EMPTY = 5,          /* modeling.py:1150-1153 */
+    HSCMP_STOP_CALLBACK = 6,       /* modeling.py:1155-1158, decided by the host between rounds */
+    HSCMP_STOP_CAPACITY = 7        /* event buffer full: re-run with a larger max_events */
+} hscmp_stop;
+
+/* keyword arguments of ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053) */
+typedef struct hscmp_params {
+    int32_t nb_nonzero_coefs;        /* nbNonzeroCoefs; < 0 = None */
+    int32_t nb_blocks;               /* nbBlocks: 1, > 1, or -1 = 'auto' (modeling.py:908-918) */
+    double tolerance_snr;            /* toleranceSnr in dB; NaN = None */
+    double tolerance_residual_scale; /* toleranceResidualScale; NaN = None */
+    double null_coeff_thres;         /* minCoefficients as passed to _selectBestAtoms (:1088); NaN = None */
+    double eps;                      /* np.finfo(D.dtype).eps (:1057) */
+    int32_t max_events;              /* capacity of the per-signal event list */
+    int32_t max_rounds;              /* selection rounds per call; <= 0 = until every signal converged */
+} hscmp_params;
+
+/* per-signal counters returned by hscmp_fetch_stats: int32 [B][HSCMP_STAT_COUNT] */
+enum { HSCMP_STAT_NNZ = 0,        /* distinct non-zero (t,k), modeling.py:1106-1111 */
+       HSCMP_STAT_DUPLICATES = 1, /* re-selections of an existing (t,k) */
+       HSCMP_STAT_ROUNDS = 2,     /* nbSelections, modeling.py:1160 */
+       HSCMP_STAT_STOP = 3,       /* hscmp_stop */
+       HSCMP_STAT_ITERATIONS = 4, /* nbIterations = applied atoms, modeling.py:1122 */
+       HSCMP_STAT_EVENTS = 5,     /* entries in the event list (== iterations) */
+       HSCMP_STAT_SLOTS = 6,      /* distinct (t,k) entries */
+       HSCMP_STAT_OFFSET = 7,     /* current half-block offset toggle, modeling.py:1163 */
+       HSCMP_STAT_COUNT = 8 };
+
+int hscmp_version(void);
+
+/* One context per GPU (or per host thread).  device_id: HIP ordinal. */
+int hscmp_create(hscmp_ctx** out, int device_id);
+void hscmp_destroy(hscmp_ctx* ctx);
+const char* hscmp_last_error(hscmp_ctx* ctx);
+
+/* Queue all work of this context on `hip_stream` (a hipStream_t; NULL = the context's own
+ * stream).  hscmp_synchronize waits for it. */
+int hscmp_set_stream(hscmp_ctx* ctx, void* hip_stream);
+int hscmp_synchronize(hscmp_ctx* ctx);
+
+/* Dictionary D [K][W][F] and optional selection weights [K] (modeling.py:902-906), host
+ * pointers; replaces the `D` / `weights` arguments of computeCoefficients (:1053).
+ * The dictionary stays resident on the GPU until replaced. */
+int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W, int F, hscmp_dtype dtype,
+                         const void* weights);
+
+/* modeling.py:149-188 convolve1d(sequence, filters, padding): x [T][F] host -> out [Tout][K]
+ * host; same != 0: zero-padded 'same' (Tout = T), else 'valid' (Tout = T-W+1).  Uses the
+ * dictionary of the context. */
+int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, void* out);
+
+/* ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053-1169) for a batch of B
+ * independent signals x [B][T][F] (host memory): initial correlation, then the greedy
+ * select / subtract / local re-correlate loop, entirely on the GPU.  Results stay in the
+ * context until fetched. */
+int hscmp_encode_batch(hscmp_ctx* ctx, const void* x, int B, int T, const hscmp_params* params);
+
+/* Same, x_dev already resident in GPU memory (device pointer, same layout); asynchronous on the
+ * context's stream. */
+int hscmp_encode_batch_device(hscmp_ctx* ctx, const void* x_dev, int B, int T, const hscmp_params* params);
+
+/* Run up to max_rounds further selection rounds on the signals that have not converged
+ * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
+ * between rounds.  max_rounds <= 0: until converged. */
+int hscmp_continue(hscmp_ctx* ctx, int max_rounds);
+
+/* Mark signal b as converged by the host-side stopCondition (modeling.py:1155-1158). */
+int hscmp_stop_signal(hscmp_ctx* ctx, int b);
+
+/* Results of the last encode (host buffers, any may be NULL):
+ *   ev_t, ev_k  int32 [B][max_events]   selected positions / atom indices IN SELECTION ORDER
+ *   ev_c        dtype [B][max_events]   coefficient of each selection (modeling.py:970,946)
+ *   stats       int32 [B][HSCMP_STAT_COUNT]
+ *   residual    dtype [B][T][F]         (modeling.py:1071,1117)
+ *   energies    double [B][2]           signal energy, tracked residual energy (:1070,1014) */
+int hscmp_fetch_events(hscmp_ctx* ctx, int32_t* ev_t, int32_t* ev_k, void* ev_c);
+int hscmp_fetch_stats(hscmp_ctx* ctx, int32_t* stats);
+int hscmp_fetch_residual(hscmp_ctx* ctx, void* residual);
+int hscmp_fetch_energies(hscmp_ctx* ctx, double* energies);
+
+/* Accumulated coefficients (the float64 `coefficients[t,k] += c` of modeling.py:1114,:992) as
+ * distinct (t,k) slots in first-selection order: slot_t, slot_k int32 [B][max_events],
+ * slot_acc double [B][max_events]; counts in stats[HSCMP_STAT_SLOTS]. */
+int hscmp_fetch_slots(hscmp_ctx* ctx, int32_t* slot_t, int32_t* slot_k, double* slot_acc);
+
+/* Device pointers of the result arrays (for callers that keep everything on the GPU, e.g. the
+ * multi-GPU gather and bench.py); valid until the next encode with a larger shape. */
+typedef struct hscmp_device_view {
+    int32_t B, T, F, K, W, max_events, dtype, reserved;
+    void* ev_t; void* ev_k; void* ev_c; void* stats; void* residual; void* energies;
+    void* best_c; void* best_k;   /* per-position best coefficient / atom (table-free state) */
+} hscmp_device_view;
+int hscmp_get_device_view(hscmp_ctx* ctx, hscmp_device_view* view);
+
+/* Durations (ms, HIP events on the context's stream) of the kernels of the last encode:
+ * out[0] = prepare (copy + signal energy), out[1] = initial correlation (modeling.py:1077),
+ * out[2] = greedy loop (modeling.py:1086-1163), out[3] = reserved. */
+int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4);
+
+/* Name of the kernel variant the last encode dispatched ("mfma_f32", "generic_f64", ...). */
+const char* hscmp_last_variant(hscmp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
