@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 using namespace hscmp;
 
@@ -32,7 +33,7 @@ struct hscmp_ctx {
     // batch workspace
     int B = 0, T = 0, cap = 0, maxsel = 0;
     bool have_batch = false;
-    size_t cap_resid = 0, cap_best = 0, cap_ev = 0, cap_sel = 0, cap_stats = 0, cap_x = 0;
+    size_t caps[16] = {0};
     void* d_x = nullptr;      // staging for host inputs
     void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
@@ -162,16 +163,6 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     return HSCMP_OK;
 }
 
-template <typename T> static int grow(hscmp_ctx* ctx, T** p, size_t* cap, size_t bytes)
-{
-    if (*p && *cap >= bytes) return HSCMP_OK;
-    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-    hipError_t e = hipMalloc((void**)p, bytes);
-    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-    *cap = bytes;
-    return HSCMP_OK;
-}
-
 static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevParams* out)
 {
     DevParams P{};
@@ -206,46 +197,38 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
     return HSCMP_OK;
 }
 
+// every buffer tracks its own capacity in bytes (element size changes with the dictionary dtype)
+struct BufCap { void** p; size_t* cap; size_t bytes; };
+
 static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
 {
     const size_t es = esize(ctx->dtype);
     const size_t B = P.B, TF = (size_t)P.T * P.F, T = P.T, cap = P.cap, ms = P.maxsel;
-    int rc;
-    size_t c;
-    if (need_x && (rc = grow(ctx, (char**)&ctx->d_x, &ctx->cap_x, B * TF * es))) return rc;
-    if ((rc = grow(ctx, (char**)&ctx->d_resid, &ctx->cap_resid, B * TF * es))) return rc;
-    // best_c / best_k share one capacity counter: grow both when either is short
-    if (!ctx->d_best_c || ctx->cap_best < B * T) {
-        if (ctx->d_best_c) { (void)hipFree(ctx->d_best_c); ctx->d_best_c = nullptr; }
-        if (ctx->d_best_k) { (void)hipFree(ctx->d_best_k); ctx->d_best_k = nullptr; }
-        c = 0; if ((rc = grow(ctx, (char**)&ctx->d_best_c, &c, B * T * es))) return rc;
-        c = 0; if ((rc = grow(ctx, &ctx->d_best_k, &c, B * T * sizeof(int)))) return rc;
-        ctx->cap_best = B * T;
-    }
-    if (!ctx->d_ev_t || ctx->cap_ev < B * cap) {
-        void** ps[] = {(void**)&ctx->d_ev_t, (void**)&ctx->d_ev_k, (void**)&ctx->d_ev_c, (void**)&ctx->d_slot_t, (void**)&ctx->d_slot_k, (void**)&ctx->d_slot_a};
-        size_t sz[] = {4, 4, es, 4, 4, 8};
-        for (int i = 0; i < 6; ++i) {
-            if (*ps[i]) { (void)hipFree(*ps[i]); *ps[i] = nullptr; }
-            c = 0; if ((rc = grow(ctx, (char**)ps[i], &c, B * cap * sz[i]))) return rc;
-        }
-        ctx->cap_ev = B * cap;
-    }
-    if (!ctx->d_sel_t || ctx->cap_sel < B * 2 * ms) {
-        void** ps[] = {(void**)&ctx->d_sel_t, (void**)&ctx->d_sel_k, (void**)&ctx->d_sel_c};
-        size_t sz[] = {4, 4, es};
-        for (int i = 0; i < 3; ++i) {
-            if (*ps[i]) { (void)hipFree(*ps[i]); *ps[i] = nullptr; }
-            c = 0; if ((rc = grow(ctx, (char**)ps[i], &c, B * 2 * ms * sz[i]))) return rc;
-        }
-        ctx->cap_sel = B * 2 * ms;
-    }
-    if (!ctx->d_stats || ctx->cap_stats < B) {
-        if (ctx->d_stats) { (void)hipFree(ctx->d_stats); ctx->d_stats = nullptr; }
-        if (ctx->d_energy) { (void)hipFree(ctx->d_energy); ctx->d_energy = nullptr; }
-        c = 0; if ((rc = grow(ctx, &ctx->d_stats, &c, B * ST_COUNT * sizeof(int)))) return rc;
-        c = 0; if ((rc = grow(ctx, (char**)&ctx->d_energy, &c, B * 2 * es))) return rc;
-        ctx->cap_stats = B;
+    BufCap bufs[] = {
+        {(void**)&ctx->d_x, &ctx->caps[0], need_x ? B * TF * es : 0},
+        {(void**)&ctx->d_resid, &ctx->caps[1], B * TF * es},
+        {(void**)&ctx->d_best_c, &ctx->caps[2], B * T * es},
+        {(void**)&ctx->d_best_k, &ctx->caps[3], B * T * sizeof(int)},
+        {(void**)&ctx->d_ev_t, &ctx->caps[4], B * cap * 4},
+        {(void**)&ctx->d_ev_k, &ctx->caps[5], B * cap * 4},
+        {(void**)&ctx->d_ev_c, &ctx->caps[6], B * cap * es},
+        {(void**)&ctx->d_slot_t, &ctx->caps[7], B * cap * 4},
+        {(void**)&ctx->d_slot_k, &ctx->caps[8], B * cap * 4},
+        {(void**)&ctx->d_slot_a, &ctx->caps[9], B * cap * 8},
+        {(void**)&ctx->d_sel_t, &ctx->caps[10], B * 2 * ms * 4},
+        {(void**)&ctx->d_sel_k, &ctx->caps[11], B * 2 * ms * 4},
+        {(void**)&ctx->d_sel_c, &ctx->caps[12], B * 2 * ms * es},
+        {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
+        {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
+    };
+    bool stream_idle = false;
+    for (const BufCap& b : bufs) {
+        if (b.bytes == 0 || (*b.p && *b.cap >= b.bytes)) continue;
+        if (!stream_idle) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); stream_idle = true; }
+        if (*b.p) { (void)hipFree(*b.p); *b.p = nullptr; *b.cap = 0; }
+        hipError_t e = hipMalloc(b.p, b.bytes);
+        if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", b.bytes, hipGetErrorString(e));
+        *b.cap = b.bytes;
     }
     return HSCMP_OK;
 }
