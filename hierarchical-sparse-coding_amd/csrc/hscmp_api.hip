@@ -168,9 +168,7 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
     DevParams P{};
     P.B = B; P.T = T; P.K = ctx->K; P.W = ctx->W; P.F = ctx->F;
     P.off = (ctx->W - 1) / 2;
-    int seg = 64;
-    while ((T + seg - 1) / seg > kMaxSeg) seg <<= 1;
-    P.seg = seg; P.nseg = (T + seg - 1) / seg;
+    set_segments(P, kMaxSeg);
     if (p->nb_blocks == 1) { P.blocked = 0; P.bs = 0; P.nbk = 0; P.maxsel = 1; }
     else {
         // modeling.py:908-918
@@ -251,10 +249,14 @@ static bool use_mfma(const hscmp_ctx* ctx)
     return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr;
 }
 
-template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams& P)
+template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams& P0)
 {
     State<R> S = make_state<R>(ctx);
-    hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S);
+    DevParams P = P0;
+    set_segments(P, GenericRecorr<R>::kMaxSegments);
+    const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16;
+    hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S,
+                       typename GenericRecorr<R>::Args{});
     return HSCMP_OK;
 }
 

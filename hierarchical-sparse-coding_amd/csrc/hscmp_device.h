@@ -37,6 +37,15 @@ struct DevParams {
     int max_rounds;     // <= 0: until converged
 };
 
+// segment size: the smallest power of two >= 64 that keeps the segment count within maxseg
+inline void set_segments(DevParams& P, int maxseg)
+{
+    int seg = 64;
+    while ((P.T + seg - 1) / seg > maxseg) seg <<= 1;
+    P.seg = seg;
+    P.nseg = (P.T + seg - 1) / seg;
+}
+
 enum { ST_NNZ = 0, ST_DUP = 1, ST_ROUNDS = 2, ST_STOP = 3, ST_ITERS = 4, ST_EVENTS = 5, ST_SLOTS = 6,
        ST_OFFSET = 7, ST_COUNT = 8 };
 enum { STOP_RUNNING = 0, STOP_ENERGY_EPS = 1, STOP_NNZ = 2, STOP_SNR = 3, STOP_SCALE = 4, STOP_EMPTY = 5,

@@ -89,12 +89,12 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
 // ------------------------------------------------------------------------------------------------
 // shared state of the greedy loop
 // ------------------------------------------------------------------------------------------------
-template <typename R> struct IterShared {
-    R seg_score[kMaxSeg];
-    R seg_c[kMaxSeg];
-    int seg_t[kMaxSeg];
-    int seg_k[kMaxSeg];
-    R rseg[kMaxSeg];          // max |residual| per segment (toleranceResidualScale only)
+template <typename R, int MAXSEG> struct IterSharedT {
+    R seg_score[MAXSEG];
+    R seg_c[MAXSEG];
+    int seg_t[MAXSEG];
+    int seg_k[MAXSEG];
+    R rseg[MAXSEG];           // max |residual| per segment (toleranceResidualScale only)
     R part_s[kThreads];
     R part_c[kThreads];
     int part_k[kThreads];
@@ -128,8 +128,8 @@ __device__ __forceinline__ Cand<R> wave_range_argmax(const Sig<R>& G, const R* w
     return wave_argmax(best);
 }
 
-template <typename R>
-__device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G, const R* w, IterShared<R>& sh, int sg, int lane)
+template <typename R, typename SH>
+__device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
 {
     const int t0 = sg * P.seg;
     const int t1 = min(P.T, t0 + P.seg);
@@ -143,8 +143,8 @@ __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G
     }
 }
 
-template <typename R>
-__device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& G, IterShared<R>& sh, int sg, int lane)
+template <typename R, typename SH>
+__device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& G, SH& sh, int sg, int lane)
 {
     const int64_t i0 = (int64_t)sg * P.seg * P.F;
     const int64_t i1 = (int64_t)min(P.T, (sg + 1) * P.seg) * P.F;
@@ -155,9 +155,9 @@ __device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& 
 }
 
 // block-wide stable compaction of list entries [0,n) with predicate pred(i): src -> dst; returns count
-template <typename R, typename Pred>
+template <typename R, typename SH, typename Pred>
 __device__ __forceinline__ int block_compact(int n, Pred pred, const int* st, const int* sk, const R* sc,
-                                              int* dt, int* dk, R* dc, IterShared<R>& sh)
+                                              int* dt, int* dk, R* dc, SH& sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int running = 0;
@@ -183,8 +183,8 @@ __device__ __forceinline__ int block_compact(int n, Pred pred, const int* st, co
 }
 
 // energy of the clipped window centred at t, pinned order; result valid in thread 0
-template <typename R>
-__device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R>& G, IterShared<R>& sh, int t, int& len)
+template <typename R, typename SH>
+__device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R>& G, SH& sh, int t, int& len)
 {
     int s, e, es;
     len = centered_span(P.T, P.W, t, s, e, es);
@@ -204,9 +204,14 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
 // Threads = (row, atom group); the per-atom fma chain order is the pinned one (f outer, w inner).
 // ------------------------------------------------------------------------------------------------
 template <typename R> struct GenericRecorr {
-    static constexpr size_t dynamic_lds_bytes(const DevParams&) { return 0; }
+    static constexpr int kMaxSegments = kMaxSeg;
+    using Shared = IterSharedT<R, kMaxSeg>;
+    struct Args {};                                     // no extra kernel arguments
+    static size_t extra_lds_bytes(const DevParams&) { return 0; }
+    static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
+    template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G,
-                                               IterShared<R>& sh, int p)
+                                               SH& sh, const Args&, char*, int p)
     {
         const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x;
         const int nrows = 2 * W - 1;
@@ -262,9 +267,14 @@ template <typename R> struct GenericRecorr {
 // the greedy loop            grid = B, block = kThreads, one persistent workgroup per signal
 // ------------------------------------------------------------------------------------------------
 template <typename R, typename Recorr>
-__global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R> S)
+__global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
 {
-    __shared__ IterShared<R> sh;
+    // all LDS comes from ONE dynamic array (16-byte aligned base): control block first, then the
+    // policy's region (dictionary image, residual window)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using SH = typename Recorr::Shared;
+    SH& sh = *reinterpret_cast<SH*>(smem);
+    char* plds = smem + ((sizeof(SH) + 15) / 16) * 16;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int* stats = S.stats + (int64_t)b * ST_COUNT;
     if (stats[ST_STOP] != STOP_RUNNING) return;          // converged in an earlier launch
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
     const R* __restrict__ wts = S.weights;
+    Recorr::prologue(P, S, A, plds);
 
     // ---- prologue: segment maxima of the per-position best (and of |residual|)
     for (int sg = wv; sg < P.nseg; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
 
             // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
-            Recorr::run(P, S, G, sh, p);
+            Recorr::run(P, S, G, sh, A, plds, p);
             __syncthreads();
 
             // ---- refresh the maxima of the touched segments
