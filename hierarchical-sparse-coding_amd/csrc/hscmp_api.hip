@@ -489,3 +489,13 @@ extern "C" int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ctx->dtype == HSCMP_F32 ? run_convolve<float>(ctx, x, T, same, out) : run_convolve<double>(ctx, x, T, same, out);
 }
+
+#ifdef HSCMP_DBG_STAMPS
+// diagnostic build only
+extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hscmp::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hscmp::g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

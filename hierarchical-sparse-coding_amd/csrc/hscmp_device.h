@@ -22,6 +22,7 @@ struct DevParams {
     int B, T, K, W, F;
     int off;            // (W-1)/2: lead of the centred window (modeling.py:159-164, utils.py:84-99)
     int seg, nseg;      // segment size (power of two >= 64) and count, nseg <= kMaxSeg
+    int seg_shift;      // log2(seg)
     // selection (modeling.py:899-982)
     int blocked;        // 0: single arg-max; 1: blocked
     int bs, nbk;        // block size (even) and base block count ceil(T/bs)
@@ -40,9 +41,10 @@ struct DevParams {
 // segment size: the smallest power of two >= 64 that keeps the segment count within maxseg
 inline void set_segments(DevParams& P, int maxseg)
 {
-    int seg = 64;
-    while ((P.T + seg - 1) / seg > maxseg) seg <<= 1;
+    int seg = 64, shift = 6;
+    while ((P.T + seg - 1) / seg > maxseg) { seg <<= 1; ++shift; }
     P.seg = seg;
+    P.seg_shift = shift;
     P.nseg = (P.T + seg - 1) / seg;
 }
 
@@ -92,6 +94,44 @@ template <typename R> __device__ __forceinline__ Cand<R> wave_argmax(Cand<R> c)
         if (better(o, c)) c = o;
     }
     return c;
+}
+
+// float specialisation on DPP (data-parallel primitives: VALU-speed lane exchanges instead of the
+// LDS-crossbar ds_bpermute behind __shfl_xor): quad swaps, half-row and row mirrors bring every
+// 16-lane row to its own arg-max -- `better` is symmetric, so mirrored partners are as good as xor
+// partners -- then the four row results are read out with v_readlane and merged.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ void argmax_step(Cand<float>& c)
+{
+    Cand<float> o;
+    o.s = dpp_f<CTRL>(c.s);
+    o.i = dpp_i<CTRL>(c.i);
+    if (better(o, c)) c = o;
+}
+template <> __device__ __forceinline__ Cand<float> wave_argmax<float>(Cand<float> c)
+{
+    argmax_step<0xB1>(c);     // quad_perm [1,0,3,2]
+    argmax_step<0x4E>(c);     // quad_perm [2,3,0,1]
+    argmax_step<0x141>(c);    // row_half_mirror
+    argmax_step<0x140>(c);    // row_mirror: every row of 16 lanes now holds its arg-max
+    Cand<float> r;
+    r.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 0));
+    r.i = __builtin_amdgcn_readlane(c.i, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        Cand<float> o;
+        o.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 16 * row));
+        o.i = __builtin_amdgcn_readlane(c.i, 16 * row);
+        if (better(o, r)) r = o;
+    }
+    return r;
 }
 
 template <typename R> __device__ __forceinline__ R wave_max(R v)

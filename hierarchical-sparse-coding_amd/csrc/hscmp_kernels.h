@@ -89,15 +89,15 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
 // ------------------------------------------------------------------------------------------------
 // shared state of the greedy loop
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MAXSEG> struct IterSharedT {
+template <typename R, int MAXSEG, bool WITH_PART = true> struct IterSharedT {
     R seg_score[MAXSEG];
     R seg_c[MAXSEG];
     int seg_t[MAXSEG];
     int seg_k[MAXSEG];
     R rseg[MAXSEG];           // max |residual| per segment (toleranceResidualScale only)
-    R part_s[kThreads];
-    R part_c[kThreads];
-    int part_k[kThreads];
+    R part_s[WITH_PART ? kThreads : 1];       // GenericRecorr's cross-group merge buffers
+    R part_c[WITH_PART ? kThreads : 1];
+    int part_k[WITH_PART ? kThreads : 1];
     R red[2 * kWaves];
     Cand<R> cred[kWaves];
     int wtot[kWaves];
@@ -131,7 +131,7 @@ __device__ __forceinline__ Cand<R> wave_range_argmax(const Sig<R>& G, const R* w
 template <typename R, typename SH>
 __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
 {
-    const int t0 = sg * P.seg;
+    const int t0 = (sg << P.seg_shift);
     const int t1 = min(P.T, t0 + P.seg);
     Cand<R> win = wave_range_argmax(G, w, t0, t1, lane);
     if (lane == 0) {
@@ -146,8 +146,8 @@ __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G
 template <typename R, typename SH>
 __device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& G, SH& sh, int sg, int lane)
 {
-    const int64_t i0 = (int64_t)sg * P.seg * P.F;
-    const int64_t i1 = (int64_t)min(P.T, (sg + 1) * P.seg) * P.F;
+    const int64_t i0 = (int64_t)(sg << P.seg_shift) * P.F;
+    const int64_t i1 = (int64_t)min(P.T, ((sg + 1) << P.seg_shift)) * P.F;
     R m = (R)0;
     for (int64_t i = i0 + lane; i < i1; i += 64) { const R a = rabs(G.r[i]); m = a > m ? a : m; }
     m = wave_max(m);
@@ -205,6 +205,7 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
 // ------------------------------------------------------------------------------------------------
 template <typename R> struct GenericRecorr {
     static constexpr int kMaxSegments = kMaxSeg;
+    static constexpr bool kFused = false;               // uses the step-by-step atom body of iterate_kernel
     using Shared = IterSharedT<R, kMaxSeg>;
     struct Args {};                                     // no extra kernel arguments
     static size_t extra_lds_bytes(const DevParams&) { return 0; }
@@ -309,26 +310,42 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         int nsel;
         // =========================== select (modeling.py:899-982) ===========================
+        int p_sel = 0, k_sel = 0;
+        R c_sel = (R)0;
         if (!P.blocked) {
             // :965-975 flat arg-max == arg-max over the segment maxima (ties: lowest t, then k)
-            Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
-            for (int i = tid; i < P.nseg; i += kThreads) {
-                Cand<R> o; o.s = sh.seg_score[i]; o.i = i;
-                if (better(o, c)) c = o;
+            if constexpr (Recorr::kFused) {
+                // every wave scans all segment maxima redundantly: no cross-wave combine, no barrier
+                Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
+                for (int i = lane; i < P.nseg; i += 64) {
+                    Cand<R> o; o.s = sh.seg_score[i]; o.i = i;
+                    if (better(o, c)) c = o;
+                }
+                c = wave_argmax(c);
+                const int sg = c.i;
+                p_sel = sh.seg_t[sg]; k_sel = sh.seg_k[sg]; c_sel = sh.seg_c[sg];
+                nsel = (has_thres && !(fabs((double)c_sel) > thres)) ? 0 : 1;     // :974
+            } else {
+                Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
+                for (int i = tid; i < P.nseg; i += kThreads) {
+                    Cand<R> o; o.s = sh.seg_score[i]; o.i = i;
+                    if (better(o, c)) c = o;
+                }
+                c = wave_argmax(c);
+                if (lane == 0) sh.cred[wv] = c;
+                __syncthreads();
+                if (tid == 0) {
+                    Cand<R> m = sh.cred[0];
+                    for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
+                    const int sg = m.i;
+                    const R cc = sh.seg_c[sg];
+                    sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
+                    sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
+                }
+                __syncthreads();
+                nsel = sh.nsel;
+                p_sel = sh.atom_t; k_sel = sh.atom_k; c_sel = sh.atom_c;
             }
-            c = wave_argmax(c);
-            if (lane == 0) sh.cred[wv] = c;
-            __syncthreads();
-            if (tid == 0) {
-                Cand<R> m = sh.cred[0];
-                for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
-                const int sg = m.i;
-                const R cc = sh.seg_c[sg];
-                sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
-                sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
-            }
-            __syncthreads();
-            nsel = sh.nsel;
         } else {
             // :908-937 one arg-max per block of bs samples (half-block shifted when offset is set)
             const int off = sh.offset;
@@ -401,10 +418,16 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         }
 
         // =========================== apply the selected atoms (:1101-1142) ===========================
+        bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
         for (int ai = 0; ai < nsel; ++ai) {
             int p, k; R c;
-            if (!P.blocked) { p = sh.atom_t; k = sh.atom_k; c = sh.atom_c; }
+            if (!P.blocked) { p = p_sel; k = k_sel; c = c_sel; }
             else { p = ord_t[ai]; k = ord_k[ai]; c = ord_c[ai]; }
+            if constexpr (Recorr::kFused) {
+                // policy-owned atom body: one batch of global loads, three barriers (hscmp_mfma.h)
+                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c)) { fused_stop = true; break; }
+                continue;
+            }
 
             // ---- :1106-1114 duplicate / nnz bookkeeping, coefficient accumulation, event append
             if (tid == 0) sh.found = -1;
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
             __syncthreads();                         // residual writes visible to the whole workgroup
             if (P.has_scale) {
-                const int sg0 = s / P.seg, sg1 = (e - 1) / P.seg;
+                const int sg0 = s >> P.seg_shift, sg1 = (e - 1) >> P.seg_shift;
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
             }
 
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             // ---- refresh the maxima of the touched segments
             {
                 const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
-                const int sg0 = lo / P.seg, sg1 = hi / P.seg;
+                const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
             }
 
@@ -485,6 +508,15 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         }
 
         // =========================== slow stop rules (:1145-1163) ===========================
+        if constexpr (Recorr::kFused) {
+            // single arg-max rounds without a residual-scale rule need no further synchronisation:
+            // the stop decision already went through apply_atom's last barrier
+            if (!P.blocked && !P.has_scale && nsel > 0) {
+                if (tid == 0) { sh.rounds += 1; sh.offset = !sh.offset; }
+                if (fused_stop) break;
+                continue;
+            }
+        }
         if (P.has_scale) {
             R m = (R)0;
             for (int i = tid; i < P.nseg; i += kThreads) { const R a = sh.rseg[i]; m = a > m ? a : m; }
@@ -506,6 +538,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         if (sh.converged) break;
     }
 
+    __syncthreads();
     if (tid == 0) {
         stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;
         stats[ST_ITERS] = sh.iters; stats[ST_EVENTS] = sh.nev; stats[ST_SLOTS] = sh.nslots; stats[ST_OFFSET] = sh.offset;

@@ -25,6 +25,8 @@
 
 #include "hscmp_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace hscmp {
@@ -73,40 +75,108 @@ inline void mfma_build_dict_image(const float* D, int K, int W, int F, std::vect
 // One 32-position tile against all atom groups: per-position best (coefficient, atom).
 //   dimg : LDS dictionary image;  win : LDS floats, win[j + kk + 2s] is the B operand (see above)
 //   wts  : LDS weights [32*G] (HAS_W) ;  result valid in lanes 0..31 (position = lane)
-// S4C > 0: compile-time chunk count (B operands live in registers); S4C == 0: runtime count.
+// S4C > 0: compile-time chunk count -- B operands live in registers, A operands and accumulators
+// are double buffered: group g+1's A fragments are fetched while group g's MFMA chain runs, and
+// the lane-local arg-max of group g-1 is interleaved between the MFMA issues of group g.
+// S4C == 0: runtime chunk count (any W), simple loop.
 // ------------------------------------------------------------------------------------------------
+// value of the same lane index in the OTHER half-wave (lane ^ 32) through v_permlane32_swap:
+// swap(a, a) leaves r[0] = {low half of a, low half of a} and r[1] = {high half, high half}
+__device__ __forceinline__ int swap_halves_i(int v, int h)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return h ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ float swap_halves_f(float v, int h) { return __int_as_float(swap_halves_i(__float_as_int(v), h)); }
+
+template <bool HAS_W>
+__device__ __forceinline__ void mfma_reduce_elem(float v, int k, const float* __restrict__ wts, float& bs, float& bc, int& bk)
+{
+#ifdef HSCMP_DBG_NO_REDUCE   // diagnostic build: keep the accumulator live, skip the arg-max
+    asm volatile("" :: "v"(v));
+    (void)k; (void)wts; (void)bs; (void)bc; (void)bk;
+#else
+    float s;
+    if (HAS_W) { const float sw = v * wts[k]; s = fabsf(sw); } else s = fabsf(v);
+    if (s > bs) { bs = s; bc = v; bk = k; }    // ascending k, strict >: the first k wins ties
+#endif
+}
+
 template <int S4C, bool HAS_W>
 __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, const float* __restrict__ win,
                                                const float* __restrict__ wts, int G, int S4rt, int lane,
                                                float& out_c, int& out_k)
 {
-    const int S4 = S4C > 0 ? S4C : S4rt;
     const int j = lane & 31, h = lane >> 5;
     const float* wb = win + j + h;
     float bs = -1.0f, bc = 0.0f;
     int bk = 0;
-
-    float bop[S4C > 0 ? 4 * S4C : 1];
-    if (S4C > 0) {
-#pragma unroll
-        for (int s = 0; s < 4 * S4C; ++s) bop[s] = wb[2 * s];
-    }
-
     const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
-    for (int g = 0; g < G; ++g) {
-        f32x16 acc;
+
+    if constexpr (S4C > 0) {
+        constexpr int NM = 4 * S4C;            // MFMAs per atom group
+        float bop[NM];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        if (S4C > 0) {
+        for (int s = 0; s < NM; ++s) bop[s] = wb[2 * s];
+        f32x4 a0[S4C], a1[S4C];
+        f32x16 acc0, acc1;
+
+        auto load_a = [&](f32x4 (&a)[S4C], int g) {
+#ifdef HSCMP_DBG_NO_AREAD    // diagnostic build: A operands from registers, no LDS reads
 #pragma unroll
-            for (int s4 = 0; s4 < S4C; ++s4) {
-                const f32x4 a = dv[(g * S4C + s4) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bop[4 * s4 + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bop[4 * s4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bop[4 * s4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bop[4 * s4 + 3], acc, 0, 0, 0);
+            for (int s4 = 0; s4 < S4C; ++s4) { a[s4][0] = bop[s4]; a[s4][1] = bop[s4 + 1]; a[s4][2] = (float)g; a[s4][3] = bop[0]; }
+#else
+#pragma unroll
+            for (int s4 = 0; s4 < S4C; ++s4) a[s4] = dv[(g * S4C + s4) * 64];
+#endif
+        };
+        // MFMA chain of one group into `acc`; with PREV, the 16 arg-max steps of the previous
+        // group's accumulator `accp` are spread between the MFMA issues
+        auto run_first = [&](const f32x4 (&a)[S4C], f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2][m & 3], bop[m], acc, 0, 0, 0);
+        };
+        auto run_next = [&](const f32x4 (&a)[S4C], f32x16& acc, const f32x16& accp, int kbasep) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2][m & 3], bop[m], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = (m * 16) / NM; r < ((m + 1) * 16) / NM; ++r)
+                    mfma_reduce_elem<HAS_W>(accp[r], kbasep + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
             }
+        };
+        auto reduce_all = [&](const f32x16& acc, int kbase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mfma_reduce_elem<HAS_W>(acc[r], kbase + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
+        };
+        const int kb0 = 4 * h;                 // atom of accumulator element r: 32g + 4h + (r&3) + 8(r>>2)
+
+        load_a(a0, 0);
+        if (G > 1) load_a(a1, 1);
+        run_first(a0, acc0);
+        int g = 1;
+        for (; g + 1 < G; g += 2) {
+            load_a(a0, g + 1);
+            run_next(a1, acc1, acc0, 32 * (g - 1) + kb0);
+            if (g + 2 < G) load_a(a1, g + 2);
+            run_next(a0, acc0, acc1, 32 * g + kb0);
+        }
+        if (g < G) {
+            run_next(a1, acc1, acc0, 32 * (g - 1) + kb0);
+            reduce_all(acc1, 32 * g + kb0);
         } else {
+            reduce_all(acc0, 32 * (G - 1) + kb0);
+        }
+    } else {
+        const int S4 = S4rt;
+        for (int g = 0; g < G; ++g) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             for (int s4 = 0; s4 < S4; ++s4) {
                 const f32x4 a = dv[(g * S4 + s4) * 64];
                 const float b0 = wb[8 * s4 + 0], b1 = wb[8 * s4 + 2], b2 = wb[8 * s4 + 4], b3 = wb[8 * s4 + 6];
@@ -115,22 +185,16 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
             }
-        }
-        // lane-local arg-max over this lane's 16 atoms, ascending atom index, strict > (first k wins)
-        const int kbase = 32 * g + 4 * h;
+            const int kbase = 32 * g + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kbase + (r & 3) + 8 * (r >> 2);
-            const float v = acc[r];
-            float s;
-            if (HAS_W) { const float sw = v * wts[k]; s = fabsf(sw); } else s = fabsf(v);
-            if (s > bs) { bs = s; bc = v; bk = k; }
+            for (int r = 0; r < 16; ++r) mfma_reduce_elem<HAS_W>(acc[r], kbase + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
         }
     }
     // merge the two half-waves (same position, interleaved atom sets): larger score, then lower k
-    const float os = __shfl_xor(bs, 32);
-    const float oc = __shfl_xor(bc, 32);
-    const int ok = __shfl_xor(bk, 32);
+    // v_permlane32_swap (VALU speed): element [h] of the result is the value held by half-wave h
+    const float os = swap_halves_f(bs, h);
+    const float oc = swap_halves_f(bc, h);
+    const int ok = swap_halves_i(bk, h);
     if (os > bs || (os == bs && ok < bk)) { bc = oc; bk = ok; }
     out_c = bc;
     out_k = bk;
@@ -138,17 +202,35 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
 
 __device__ __forceinline__ void lds_copy_f32(float* dst, const float* __restrict__ src, int n)
 {
-    // n is a multiple of 4; 16-byte coalesced copy
+    // n is a multiple of 4; 16-byte coalesced copy, 8 loads in flight per thread before the stores
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    for (int i = threadIdx.x; i < n / 4; i += kThreads) d4[i] = s4[i];
+    const int n4 = n / 4;
+    for (int base = 0; base < n4; base += 8 * kThreads) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + threadIdx.x;
+            if (i < n4) v[u] = s4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + threadIdx.x;
+            if (i < n4) d4[i] = v[u];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // initial correlation (modeling.py:1077), zero-padded 'same', reduced to the per-position best.
-//   grid = (ceil(T / kMfmaChunk), B), block = kThreads; each wave owns every 4th 32-position tile
+//   PERSISTENT grid: gridDim.x workgroups (2 per CU) walk the (signal, chunk) items; the 64 KB
+//   dictionary image is loaded into LDS once per workgroup, the next chunk of the signal is
+//   prefetched into registers while the current one is on the matrix cores.
+//   Each wave owns every 4th 32-position tile of a chunk.
 // LDS: [dictionary image][weights 32*G][signal chunk + halo]
 // ------------------------------------------------------------------------------------------------
+constexpr int kMfmaChunkLoads = (kMfmaChunk + 128 + 32 + kThreads - 1) / kThreads;   // chunk + max taps (W<=128) + slack
+
 template <int S4C, bool HAS_W>
 __global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, State<float> S, MfmaArgs A)
 {
@@ -158,96 +240,344 @@ __global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, S
     float* dimg = reinterpret_cast<float*>(smem);
     float* wts = dimg + nd;
     float* xs = wts + 32 * G;
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = P.T;
-    const int c0 = blockIdx.x * kMfmaChunk;
-    const int npos = min(kMfmaChunk, T - c0);
     const int nx = kMfmaChunk + 8 * S4 + 32;            // chunk + taps + slack for the last tile's kk offset
+    const int cps = (T + kMfmaChunk - 1) / kMfmaChunk;  // chunks per signal
+    const int nitems = cps * P.B;
 
     lds_copy_f32(dimg, A.dimg, nd);
     if (HAS_W) for (int i = tid; i < 32 * G; i += kThreads) wts[i] = i < P.K ? S.weights[i] : 0.0f;
-    const float* x = S.residual + (int64_t)b * T;       // residual == copy of the signal at this point
-    for (int i = tid; i < nx; i += kThreads) {
-        const int g = c0 - P.off + i;                   // zero padding of 'same' (modeling.py:159-164)
-        xs[i] = (g >= 0 && g < T) ? x[g] : 0.0f;
-    }
-    __syncthreads();
 
-    const int ntiles = (npos + 31) / 32;
-    for (int q = wv; q < ntiles; q += kWaves) {
-        float c; int k;
-        mfma_tile_best<S4C, HAS_W>(dimg, xs + 32 * q, wts, G, S4, lane, c, k);
-        const int t = c0 + 32 * q + lane;
-        if (lane < 32 && t < T) {
-            S.best_c[(int64_t)b * T + t] = c;
-            S.best_k[(int64_t)b * T + t] = k;
+    float xr[kMfmaChunkLoads];
+    auto fetch = [&](int item) {                        // global -> registers (zero padding of 'same', :159-164)
+        const int b = item / cps, c0 = (item % cps) * kMfmaChunk;
+        const float* x = S.residual + (int64_t)b * T;   // residual == copy of the signal at this point
+#pragma unroll
+        for (int u = 0; u < kMfmaChunkLoads; ++u) {
+            const int i = u * kThreads + tid;
+            const int g = c0 - P.off + i;
+            xr[u] = (i < nx && g >= 0 && g < T) ? x[g] : 0.0f;
         }
+    };
+    auto stash = [&]() {                                // registers -> LDS
+#pragma unroll
+        for (int u = 0; u < kMfmaChunkLoads; ++u) {
+            const int i = u * kThreads + tid;
+            if (i < nx) xs[i] = xr[u];
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item < nitems) fetch(item);
+    for (; item < nitems; item += gridDim.x) {
+        stash();
+        __syncthreads();
+        const int next = item + gridDim.x;
+        if (next < nitems) fetch(next);                 // in flight while this chunk is computed
+        const int b = item / cps, c0 = (item % cps) * kMfmaChunk;
+        const int npos = min(kMfmaChunk, T - c0);
+        const int ntiles = (npos + 31) / 32;
+        for (int q = wv; q < ntiles; q += kWaves) {
+            float c; int k;
+            mfma_tile_best<S4C, HAS_W>(dimg, xs + 32 * q, wts, G, S4, lane, c, k);
+            const int t = c0 + 32 * q + lane;
+            if (lane < 32 && t < T) {
+                S.best_c[(int64_t)b * T + t] = c;
+                S.best_k[(int64_t)b * T + t] = k;
+            }
+        }
+        __syncthreads();                                // all tiles read xs before it is overwritten
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// MfmaRecorr: policy of iterate_kernel -- re-correlation of the 2W-1 touched rows on the matrix
-// cores.  Policy LDS: [dictionary image][weights][reflect-padded residual window]
+// MfmaRecorr: policy of iterate_kernel.  It owns the whole per-atom body (kFused): the greedy loop
+// is a chain of DEPENDENT steps, so what bounds it besides the MFMA work is the number of global
+// memory round trips and barriers per applied atom.  apply_atom() issues every global load of an
+// atom in ONE batch (residual span, the old per-position best of the touched segments, the slot
+// keys for the duplicate scan), does everything else out of LDS, and needs three barriers.
+// Policy LDS: [dictionary image][weights][residual window][squares][touched-segment buffers]
 // ------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// outstanding global stores (vmcnt), which costs a full memory round trip per barrier
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef HSCMP_DBG_STAMPS
+// diagnostic build only: per-phase cycle sums of workgroup 0 (thread 0), read back by
+// tools/time_variants.py through hscmp_debug_stamps(); never compiled into the product library
+__device__ unsigned long long g_stamps[16];
+#define HSCMP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_stamps[i] += now_ - stamp_last_; stamp_last_ = now_; } } while (0)
+#define HSCMP_STAMP_BEGIN() unsigned long long stamp_last_ = clock64()
+#else
+#define HSCMP_STAMP(i) do {} while (0)
+#define HSCMP_STAMP_BEGIN() do {} while (0)
+#endif
+
+constexpr int kBloomWords = 256;          // 8192-bit Bloom filter over the selected (t,k) pairs
+__device__ __forceinline__ unsigned bloom_hash(int t, int k)
+{
+    unsigned h = (unsigned)t * 2654435761u + (unsigned)k * 40503u;
+    h ^= h >> 15;
+    return h & (kBloomWords * 32 - 1);
+}
+
+__device__ __forceinline__ int dimg_index(int k, int w, int S4)
+{
+    // float index of D[k][w] inside Dimg[g][s4][lane][q]  (see mfma_build_dict_image)
+    return (((k >> 5) * S4 + (w >> 3)) * 64 + (k & 31) + 32 * (w & 1)) * 4 + ((w >> 1) & 3);
+}
+
 template <int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
-    using Shared = IterSharedT<float, kMfmaMaxSeg>;
+    static constexpr bool kFused = true;
+    static constexpr int kBook = 192;       // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
+    using Shared = IterSharedT<float, kMfmaMaxSeg, false>;
     using Args = MfmaArgs;
 
-    static int window_floats(int W, int S4) { return ((2 * W - 1 + 31) / 32) * 32 + 8 * S4 + 32; }
+    struct Layout { float* dimg; float* wts; float* win; float* esq; float* sbc; int* sbk; unsigned* bloom; int nwin, wp, nsbmax; };
+
+    static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + 31) / 32) * 32 + 8 * S4 + 32; }
+    static __host__ __device__ int segbuf_len(int W, int seg) { return ((2 * W - 2) / seg + 2) * seg; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A)
     {
-        return ((size_t)A.G * A.S4 * 256 + 32 * A.G + window_floats(P.W, A.S4)) * sizeof(float);
+        return ((size_t)A.G * A.S4 * 256 + (HAS_W ? 32 * A.G : 0) + window_floats(P.W, A.S4) + 2 * 8 * A.S4 +
+                2 * (size_t)segbuf_len(P.W, P.seg) + kBloomWords) * sizeof(float);
+    }
+    static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
+    {
+        const int S4 = S4C > 0 ? S4C : A.S4;
+        Layout L;
+        L.dimg = reinterpret_cast<float*>(lds);
+        L.wts = L.dimg + A.G * S4 * 256;
+        L.nwin = window_floats(P.W, S4);
+        L.wp = 8 * S4;
+        L.nsbmax = segbuf_len(P.W, P.seg);
+        L.win = L.wts + (HAS_W ? 32 * A.G : 0);
+        L.esq = L.win + L.nwin;
+        L.sbc = L.esq + 2 * L.wp;
+        L.sbk = reinterpret_cast<int*>(L.sbc + L.nsbmax);
+        L.bloom = reinterpret_cast<unsigned*>(L.sbk + L.nsbmax);
+        return L;
     }
 
     static __device__ __forceinline__ void prologue(const DevParams& P, const State<float>& S, const Args& A, char* lds)
     {
+        const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
-        const int nd = A.G * S4 * 256;
-        float* dimg = reinterpret_cast<float*>(lds);
-        float* wts = dimg + nd;
-        lds_copy_f32(dimg, A.dimg, nd);
-        if (HAS_W) for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) wts[i] = i < P.K ? S.weights[i] : 0.0f;
+        lds_copy_f32(L.dimg, A.dimg, A.G * S4 * 256);
+        if (HAS_W) for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : 0.0f;
+        for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = 0.0f;   // the tail behind the span stays zero
+        for (int i = threadIdx.x; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
+        __syncthreads();
+        // resumed launch: re-enter the (t,k) pairs selected so far
+        const int b = blockIdx.x;
+        const int nslots = S.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
+        const int* st = S.slot_t + (int64_t)b * P.cap;
+        const int* sk = S.slot_k + (int64_t)b * P.cap;
+        for (int i = threadIdx.x; i < nslots; i += kThreads) {
+            const unsigned h = bloom_hash(st[i], sk[i]);
+            atomicOr(&L.bloom[h >> 5], 1u << (h & 31));
+        }
         // visibility: the caller's next __syncthreads()
     }
 
+    // step-by-step form (used by the non-fused atom body; kept so that both bodies stay buildable)
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<float>&, const Sig<float>& Gs,
                                                SH&, const Args& A, char* lds, int p)
     {
         const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int S4 = S4C > 0 ? S4C : A.S4;
-        const int nd = A.G * S4 * 256;
-        float* dimg = reinterpret_cast<float*>(lds);
-        float* wts = dimg + nd;
-        float* win = wts + 32 * A.G;
-        const int nrows = 2 * W - 1;
-        const int ntiles = (nrows + 31) / 32;
-        const int nwin = ntiles * 32 + 8 * S4 + 32;
-        const int tstart = p - P.off - (W - 1);            // modeling.py:1028-1033
-        const int tend = p + W / 2 + (W - 1);              // :1038
-        const int sidx = tstart < 0 ? 0 : tstart;          // :1034
-        const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
-        const int nslice = eidx - sidx + 1;
-        const int span = 3 * W - 2;
-        // reflect-padded residual span (np.pad mode='reflect', :1046); zeros behind it feed only
-        // zero taps / rows that are never written
-        for (int i = tid; i < nwin; i += kThreads) {
-            float v = 0.0f;
-            if (i < span) v = Gs.r[reflect_index(tstart + i, sidx, nslice)];
-            win[i] = v;
-        }
+        const Layout L = layout(P, A, lds);
+        const int nrows = 2 * W - 1, ntiles = (nrows + 31) / 32, span = 3 * W - 2;
+        const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);
+        const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend, nslice = eidx - sidx + 1;
+        for (int i = tid; i < span; i += kThreads) L.win[i] = Gs.r[reflect_index(tstart + i, sidx, nslice)];
         __syncthreads();
         for (int q = wv; q < ntiles; q += kWaves) {
             float c; int k;
-            mfma_tile_best<S4C, HAS_W>(dimg, win + 32 * q, wts, A.G, S4, lane, c, k);
-            const int row = 32 * q + lane;
-            const int t = p - (W - 1) + row;
-            if (lane < 32 && row < nrows && t >= 0 && t < T) {      // overlapReplace clipping (utils.py:133-161)
-                Gs.bc[t] = c;
-                Gs.bk[t] = k;
+            mfma_tile_best<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane, c, k);
+            const int row = 32 * q + lane, t = p - (W - 1) + row;
+            if (lane < 32 && row < nrows && t >= 0 && t < T) { Gs.bc[t] = c; Gs.bk[t] = k; }
+        }
+    }
+
+    // One applied atom (p, k, c): modeling.py:1106-1142.  Returns true when the atom loop must stop.
+    template <typename SH>
+    static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<float>& S, const Sig<float>& Gs,
+                                                      SH& sh, const Args& A, char* lds, int p, int k, float c)
+    {
+        (void)S;
+        const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int S4 = S4C > 0 ? S4C : A.S4;
+        const Layout L = layout(P, A, lds);
+        if (sh.nev >= P.cap) {                                  // event list full (uniform: LDS value)
+            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
+            __syncthreads();
+            return true;
+        }
+        HSCMP_STAMP_BEGIN();
+        const int nrows = 2 * W - 1, ntiles = (nrows + 31) / 32, span = 3 * W - 2;
+        const int tstart = p - P.off - (W - 1);                 // :1028-1033
+        const int tend = p + W / 2 + (W - 1);                   // :1038
+        const int sidx = tstart < 0 ? 0 : tstart;               // :1034
+        const int eidx = tend > T - 1 ? T - 1 : tend;           // :1039
+        const int nslice = eidx - sidx + 1;
+        const bool interior = tstart >= 0 && tend <= T - 1;
+        int s, e, es;
+        const int len = centered_span(T, W, p, s, e, es);       // support of the atom (utils.py:103-131)
+        const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
+        const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
+        const int segbase = (sg0 << P.seg_shift);
+        const int nsb = min(T, ((sg1 + 1) << P.seg_shift)) - segbase;    // positions of the touched segments
+
+        // ---- phase A: every global load of this atom, issued together -------------------------
+        float rv[2]; int rm[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kThreads;
+            rm[u] = -1; rv[u] = 0.0f;
+            if (i < span) {                                     // np.pad 'reflect', :1046 (identity away from the edges)
+                rm[u] = interior ? tstart + i : reflect_index(tstart + i, sidx, nslice);
+                rv[u] = Gs.r[rm[u]];
             }
         }
+        float oc[2]; int ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kThreads;
+            oc[u] = 0.0f; ok[u] = 0;
+            if (i < nsb) { oc[u] = Gs.bc[segbase + i]; ok[u] = Gs.bk[segbase + i]; }
+        }
+        // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
+        const unsigned hb = bloom_hash(p, k);
+        const bool maybe_dup = ((L.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;      // uniform
+        if (maybe_dup) {
+            __syncthreads();                                    // drains thread 0's deferred slot stores
+            const int nslots = sh.nslots;
+            for (int i = tid; i < nslots; i += kThreads)
+                if (Gs.slot_t[i] == p && Gs.slot_k[i] == k) sh.found = i;      // at most one match
+        }
+
+        // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
+        const float nc = -c;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kThreads;
+            if (i < span) {
+                float v = rv[u];
+                const int m = rm[u];
+                if (m >= s && m < e) {
+                    const int q = m - s;
+                    const float prod = nc * L.dimg[dimg_index(k, es + q, S4)];   // -c*D[k] rounded, then += (utils.py:120,129)
+                    const float vn = v + prod;
+                    if (tstart + i == m) {                    // the sample itself (not a reflected copy)
+                        Gs.r[m] = vn;
+                        L.esq[q] = v * v;
+                        L.esq[L.wp + q] = vn * vn;
+                    }
+                    v = vn;
+                }
+                L.win[i] = v;
+            }
+            if (i < nsb) { L.sbc[i] = oc[u]; L.sbk[i] = ok[u]; }
+        }
+        HSCMP_STAMP(0);                                         // phase A + update, up to B1
+        if (P.has_scale) {                                      // toleranceResidualScale: max|r| of touched segments
+            __syncthreads();                                    // B1 (+ residual stores visible to the scan)
+            for (int sg = (s >> P.seg_shift) + wv; sg <= ((e - 1) >> P.seg_shift); sg += kWaves) rscan_segment(P, Gs, sh, sg, lane);
+        } else {
+            lds_barrier();                                      // B1: window, squares, segment buffers in LDS
+        }
+        HSCMP_STAMP(1);                                         // B1
+        // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
+        {
+            float pb = 0.0f, pa = 0.0f;
+            if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float ob = __shfl_down(pb, m), oa = __shfl_down(pa, m);
+                pb = pb + ob;
+                pa = pa + oa;
+            }
+            if (lane == 0) { sh.red[wv] = pb; sh.red[kWaves + wv] = pa; }
+        }
+
+        HSCMP_STAMP(2);                                         // energy partials
+        // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
+        for (int q = wv; q < ntiles; q += kWaves) {
+            float bc; int bk;
+            mfma_tile_best<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane, bc, bk);
+            const int row = 32 * q + lane, t = p - (W - 1) + row;
+            if (lane < 32 && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
+                Gs.bc[t] = bc; Gs.bk[t] = bk;
+                L.sbc[t - segbase] = bc; L.sbk[t - segbase] = bk;
+            }
+        }
+        HSCMP_STAMP(3);                                         // MFMA tile(s) of this wave
+        lds_barrier();                                          // B4: per-row results in the segment buffers
+        HSCMP_STAMP(4);                                         // B4
+
+        // ---- maxima of the touched segments, out of LDS
+        for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) {
+            const int t0 = (sg << P.seg_shift), t1 = min(T, t0 + P.seg);
+            Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
+            for (int t = t0 + lane; t < t1; t += 64) {
+                const float cc = L.sbc[t - segbase];
+                float sc;
+                if (HAS_W) { const float sw = cc * L.wts[L.sbk[t - segbase]]; sc = fabsf(sw); } else sc = fabsf(cc);
+                if (sc > best.s) { best.s = sc; best.i = t; }
+            }
+            best = wave_argmax(best);
+            if (lane == 0) {
+                sh.seg_score[sg] = best.s; sh.seg_t[sg] = best.i;
+                sh.seg_c[sg] = L.sbc[best.i - segbase]; sh.seg_k[sg] = L.sbk[best.i - segbase];
+            }
+        }
+        // ---- bookkeeping and the fast stop rules (:1106-1142) on thread 0
+        int si = -1, ev = 0;
+        bool new_slot = false;
+        double acc_old = 0.0;
+        if (tid == kBook) {
+            const float b01 = sh.red[0] + sh.red[1], b23 = sh.red[2] + sh.red[3];
+            const float a01 = sh.red[kWaves + 0] + sh.red[kWaves + 1], a23 = sh.red[kWaves + 2] + sh.red[kWaves + 3];
+            const float e_before = b01 + b23, e_after = a01 + a23;
+            const float loss = e_before - e_after;              // :1005
+            sh.e_res = sh.e_res - loss;                         // :1014
+            si = sh.found;
+            sh.found = -1;
+            if (si >= 0) { acc_old = Gs.slot_a[si]; }           // rare: re-selection of an existing (t,k)
+            if (si >= 0 && fabs(acc_old) > 0.0) sh.ndup += 1;
+            else if (fabsf(c) > 0.0f) sh.nnz += 1;
+            if (si < 0) { new_slot = true; si = sh.nslots++; L.bloom[hb >> 5] |= 1u << (hb & 31); }
+            ev = sh.nev++;
+            sh.iters += 1;
+            if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
+            else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
+            else if (P.has_snr) {
+                const float qv = sh.e_sig / sh.e_res;
+                if ((double)qv >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
+            }
+        }
+        HSCMP_STAMP(5);                                         // segment maxima + bookkeeping
+        __syncthreads();                                        // B5: also drains this atom's residual / best stores
+        HSCMP_STAMP(6);                                         // B5
+        if (tid == kBook) {
+            // deferred global stores of the bookkeeping: nobody waits for them (the duplicate scan
+            // re-synchronises before it reads the slot list), they retire under the next atom's MFMAs
+            if (new_slot) { Gs.slot_t[si] = p; Gs.slot_k[si] = k; }
+            Gs.slot_a[si] = acc_old + (double)c;                // :1114, :992  (0.0 + c for a new slot)
+            Gs.ev_t[ev] = p; Gs.ev_k[ev] = k; Gs.ev_c[ev] = c;
+        }
+        HSCMP_STAMP(7);                                         // deferred stores
+#ifdef HSCMP_DBG_STAMPS
+        if (blockIdx.x == 0 && tid == 0) g_stamps[15] += 1;
+#endif
+        return sh.converged != 0;
     }
 };
 
@@ -258,8 +588,22 @@ static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const
     const size_t lds = ((size_t)A.G * A.S4 * 256 + 32 * A.G + kMfmaChunk + 8 * A.S4 + 32) * sizeof(float);
     auto kern = corr_init_mfma_kernel<S4C, HAS_W>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    dim3 grid((P.T + kMfmaChunk - 1) / kMfmaChunk, P.B);
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, stream, P, S, A);
+    // persistent grid: as many workgroups as are resident at once (LDS-bound), capped by the work
+    static int cus = 0;          // same device family in one process: query once
+    static int per_cu = 0;       // per template instantiation
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    }
+    const int64_t nitems = (int64_t)((P.T + kMfmaChunk - 1) / kMfmaChunk) * P.B;
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > nitems) grid = nitems;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), lds, stream, P, S, A);
     return 0;
 }
 
@@ -272,6 +616,12 @@ static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P0, const 
     const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
     auto kern = iterate_kernel<float, Pol>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (getenv("HSCMP_DEBUG")) {
+        int per_cu = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds);
+        fprintf(stderr, "[hscmp] iterate_kernel<mfma S4=%d w=%d>: dynamic LDS %zu B (control %zu B), occupancy API %d blocks/CU (%s), seg=%d nseg=%d\n",
+                S4C, (int)HAS_W, lds, sizeof(typename Pol::Shared), per_cu, hipGetErrorString(e), P.seg, P.nseg);
+    }
     hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, stream, P, S, A);
     return 0;
 }

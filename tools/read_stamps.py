@@ -1,0 +1,24 @@
+"""Diagnostic: per-phase cycle shares of the fused greedy loop (libhscmp built with -DHSCMP_DBG_STAMPS)."""
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hsc_amd.synth as synth
+from hsc_amd import _native
+B = int(os.environ.get('B', '1024'))
+_native.LIB_PATH = os.path.abspath(sys.argv[1])
+D = synth.make_dictionary(256, 64, seed=2)
+x = torch.from_numpy(synth.make_batch(D, 65536, 0, 8, kind='planted', nb_atoms=256, seed=2)).cuda().repeat(B // 8, 1).contiguous()
+eng = _native.Engine(0); eng.set_dictionary(D)
+params = _native.make_params(nbNonzeroCoefs=256, eps=1.2e-7, maxEvents=576)
+lib = _native.load_library()
+out = (ctypes.c_ulonglong * 16)()
+for i in range(3):
+    eng.encode_batch_device(x.data_ptr(), B, 65536, params); eng.synchronize()
+    lib.hscmp_debug_stamps(out, 1)
+    v = np.array(list(out), dtype=np.float64)
+    n = max(v[15], 1)
+names = ['phaseA+update', 'B1', 'energy', 'MFMA tile', 'B4', 'seg+bookkeeping', 'B5', 'deferred stores']
+print('B=%d atoms=%d loop %.3f ms' % (B, n, eng.last_kernel_ms()[2]))
+for i, nm in enumerate(names):
+    print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
+print('  %-18s %8.0f cycles/atom (sum; the select between atoms is not stamped)' % ('total', v[:8].sum() / n))
