@@ -1,0 +1,166 @@
+"""Hierarchical (multilevel) convolutional sparse coding on top of the GPU matching pursuit.
+
+Reference surface (hsc/modeling.py): HierarchicalConvolutionalMatchingPursuit (:1427-1654) --
+per-level loop, distributed-coefficient post-processing, residual through the input-level
+representations -- and HierarchicalConvolutionalSparseCoder (:1671-1705).
+
+Every level runs the same engine as the single-level coder (hsc_amd.modeling): level l >= 1
+encodes the previous level's coefficient matrix [T, K_{l-1}] (float64, features = atoms of the level
+below) with the level's raw dictionary [K_l, W_l, K_{l-1}], singleton atoms down-weighted by
+`singletonWeight` in the selection score (:1448-1450).
+"""
+import collections.abc
+import copy
+
+import numpy as np
+import scipy.sparse
+
+from .modeling import ConvolutionalMatchingPursuit, ConvolutionalSparseCoder, SparseApproximator, reconstructSignal
+
+
+def _is_multilevel_dict(obj):
+    return all(hasattr(obj, a) for a in ('getNbLevels', 'getRawDictionary', 'getBaseDictionary',
+                                         'getMultiscaleDictionaries', 'countsNoSingletons'))
+
+
+class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
+    """hsc/modeling.py:1427-1654.  `method`: 'cmp' runs on the GPU engine; the reference's other
+    methods ('locomp' -- its default --, 'mptk-mp', 'mptk-cmp') are not part of this engine."""
+
+    def __init__(self, method='locomp', device=0):
+        self.method = method
+        self.device = device
+
+    def _level_coder(self, D):
+        if self.method == 'cmp':
+            return ConvolutionalSparseCoder(D, ConvolutionalMatchingPursuit(device=self.device))
+        if self.method in ('locomp', 'mptk-mp', 'mptk-cmp'):
+            raise NotImplementedError("method='%s' is not provided by the MI355X engine (greedy 'cmp' only); "
+                                      "construct HierarchicalConvolutionalMatchingPursuit(method='cmp')" % self.method)
+        raise Exception('Unsupported sparse coding method: %s' % (self.method))
+
+    def _encode_levels(self, input, coefficients, fromLevel, multilevelDict, toleranceSnr, nbBlocks, singletonWeight):
+        """Levels fromLevel .. last (:1432-1492 / :1494-1554)."""
+        for level in range(fromLevel, multilevelDict.getNbLevels()):
+            if toleranceSnr is not None and isinstance(toleranceSnr, collections.abc.Iterable):
+                targetSnr = toleranceSnr[level]
+            else:
+                targetSnr = toleranceSnr
+            D = multilevelDict.getRawDictionary(level)
+            # the first D.shape[0] - countsNoSingletons[level] atoms are singletons (:1448-1450)
+            nbSingletons = D.shape[0] - multilevelDict.countsNoSingletons[level]
+            weights = np.ones((D.shape[0],), dtype=D.dtype)
+            weights[:nbSingletons] = singletonWeight
+            levelCoder = self._level_coder(D)
+            levelCoefficients, _ = levelCoder.encode(np.asarray(input), toleranceSnr=targetSnr, nbBlocks=nbBlocks, weights=weights)
+            input = levelCoefficients.toarray()                     # :1489 (todense), next level's [T, K_l] input
+            coefficients.append(levelCoefficients)
+        return coefficients
+
+    def _forwardPhase(self, sequence, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5, stopCondition=None):
+        return self._encode_levels(sequence, [], 0, multilevelDict, toleranceSnr, nbBlocks, singletonWeight)
+
+    def _forwardPhaseFromLevel(self, sequence, coefficients, multilevelDict, toleranceSnr=None, nbBlocks=1,
+                               singletonWeight=0.5, stopCondition=None):
+        return self._encode_levels(coefficients[-1].toarray(), coefficients, len(coefficients), multilevelDict,
+                                   toleranceSnr, nbBlocks, singletonWeight)
+
+    def convertToDistributedCoefficients(self, coefficients):
+        """hsc/modeling.py:1556-1594: the singleton columns of the LAST level are handed back to the
+        level they pass through, everything else stays in the last level."""
+        last = coefficients[-1].copy()
+        if scipy.sparse.issparse(last):
+            last = last.tocsc()
+        out = []
+        for level in range(len(coefficients)):
+            if level < len(coefficients) - 1:
+                nbFeatures = coefficients[level].shape[1]
+                if scipy.sparse.issparse(coefficients[level]):
+                    levelCoefficients = last[:, :nbFeatures]
+                    last = scipy.sparse.hstack((scipy.sparse.csc_matrix((last.shape[0], nbFeatures), dtype=last.dtype),
+                                                last[:, nbFeatures:]))
+                    levelCoefficients.eliminate_zeros()
+                else:
+                    levelCoefficients = np.copy(last[:, :nbFeatures])
+                    last[:, :nbFeatures] = 0.0
+            else:
+                levelCoefficients = last
+            out.append(levelCoefficients)
+        assert len(out) == len(coefficients)
+        if scipy.sparse.issparse(coefficients[-1]):
+            assert np.sum([c.nnz for c in out]) == coefficients[-1].nnz
+        return out
+
+    def _calculateResidual(self, sequence, coefficients, multilevelDict):
+        """hsc/modeling.py:1596-1611"""
+        baseDict = multilevelDict.getBaseDictionary()
+        if baseDict.ndim == 2:
+            reconstruction = np.zeros((coefficients[0].shape[0],), dtype=coefficients[0].dtype)
+        else:
+            reconstruction = np.zeros((coefficients[0].shape[0], baseDict.shape[-1]), dtype=coefficients[0].dtype)
+        representations = multilevelDict.getMultiscaleDictionaries()
+        for level in range(multilevelDict.getNbLevels()):
+            reconstruction += reconstructSignal(coefficients[level], representations[level])
+        return sequence - reconstruction
+
+    def _postprocessCoefficients(self, coefficients, multilevelDict, returnDistributed=True):
+        """hsc/modeling.py:1613-1634"""
+        if returnDistributed:
+            return self.convertToDistributedCoefficients(coefficients)
+        out = []
+        for level in range(multilevelDict.getNbLevels()):
+            c = coefficients[level]
+            if level < multilevelDict.getNbLevels() - 1:      # keep the last level only
+                c = scipy.sparse.csc_matrix(c.shape, dtype=c.dtype) if scipy.sparse.issparse(c) else np.zeros_like(c)
+            out.append(c)
+        return out
+
+    def computeCoefficients(self, sequence, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
+                            nbBlocks=1, minCoefficients=None, singletonWeight=0.5, returnDistributed=True, stopCondition=None):
+        """hsc/modeling.py:1636-1643"""
+        assert _is_multilevel_dict(multilevelDict)
+        coefficients = self._forwardPhase(sequence, multilevelDict, toleranceSnr, nbBlocks, singletonWeight, stopCondition)
+        coefficients = self._postprocessCoefficients(coefficients, multilevelDict, returnDistributed)
+        residual = self._calculateResidual(sequence, coefficients, multilevelDict)
+        return coefficients, residual
+
+    def computeCoefficientsFromLevel(self, sequence, coefficients, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None,
+                                     toleranceSnr=None, nbBlocks=1, minCoefficients=None, singletonWeight=0.5, stopCondition=None,
+                                     returnDistributed=True):
+        """hsc/modeling.py:1645-1654"""
+        assert _is_multilevel_dict(multilevelDict)
+        coefficients = copy.deepcopy(coefficients)
+        coefficients = self._forwardPhaseFromLevel(sequence, coefficients, multilevelDict, toleranceSnr, nbBlocks,
+                                                   singletonWeight, stopCondition)
+        return self._postprocessCoefficients(coefficients, multilevelDict, returnDistributed)
+
+
+class HierarchicalConvolutionalSparseCoder(object):
+    """hsc/modeling.py:1671-1705"""
+
+    def __init__(self, multilevelDict, approximator):
+        assert _is_multilevel_dict(multilevelDict)
+        if not multilevelDict.hasSingletonBases:
+            multilevelDict = multilevelDict.withSingletonBases()
+        self.multilevelDict = multilevelDict
+        self.approximator = approximator
+
+    def encode(self, sequence, *args, **kwargs):
+        assert sequence.ndim == 1 or sequence.ndim == 2
+        return self.approximator.computeCoefficients(sequence, self.multilevelDict, *args, **kwargs)
+
+    def encodeFromLevel(self, sequence, coefficients, *args, **kwargs):
+        assert len(coefficients) > 0
+        return self.approximator.computeCoefficientsFromLevel(sequence, coefficients, self.multilevelDict, *args, **kwargs)
+
+    def reconstruct(self, coefficients):
+        assert len(coefficients) > 0
+        baseDict = self.multilevelDict.getBaseDictionary()
+        if baseDict.ndim == 2:
+            signal = np.zeros((coefficients[0].shape[0],), dtype=coefficients[0].dtype)
+        else:
+            signal = np.zeros((coefficients[0].shape[0], baseDict.shape[-1]), dtype=coefficients[0].dtype)
+        representations = self.multilevelDict.getMultiscaleDictionaries()
+        for level in range(self.multilevelDict.getNbLevels()):
+            signal += reconstructSignal(coefficients[level], representations[level])
+        return signal

@@ -259,3 +259,12 @@ class ConvolutionalSparseCoder(object):
     def reconstruct(self, coefficients):
         assert coefficients.ndim == 1 or coefficients.ndim == 2
         return reconstructSignal(coefficients, self.D)
+
+
+# The hierarchical encoder (hsc/modeling.py:1427-1705) lives in hsc_amd.hierarchical and is reachable
+# from here under the reference's names (lazy, PEP 562: hierarchical itself imports this module).
+def __getattr__(name):
+    if name in ('HierarchicalConvolutionalMatchingPursuit', 'HierarchicalConvolutionalSparseCoder'):
+        from . import hierarchical
+        return getattr(hierarchical, name)
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))

@@ -1,0 +1,124 @@
+"""Hierarchical encoder (hsc/modeling.py:1427-1705) and the MultilevelDictionary container
+(hsc/dataset.py:110-410) against golden vectors of the real reference (tests/golden/hsc_small.npz).
+
+CPU tests run the per-level loop with the level coder replaced by the CPU oracle (test
+infrastructure) -- they check the host logic: weights, per-level SNR, densification, distributed
+post-processing, residual.  The -m gpu tests run the product path (GPU engine)."""
+import numpy as np
+import pytest
+import scipy.sparse
+
+import golden_util as gu
+
+
+def _golden():
+    return gu.load('hsc_small.npz')
+
+
+def _mld():
+    from hsc_amd.dataset import MultilevelDictionary
+    z = _golden()
+    dicts = [z['raw0'], z['raw1'], z['raw2']]
+    return MultilevelDictionary.fromRawDictionaries(dicts, [int(s) for s in z['scales']])
+
+
+def test_multilevel_dictionary_matches_reference():
+    z = _golden()
+    mld = _mld()
+    for l in range(3):
+        assert np.allclose(mld.getMultiscaleDictionaries()[l], z['rep%d' % l], atol=1e-7)
+    mlds = mld.withSingletonBases()
+    assert mlds.hasSingletonBases
+    assert np.array_equal(mlds.counts, z['counts'])
+    assert np.array_equal(mlds.countsNoSingletons, z['countsNoSingletons'])
+    for l in range(3):
+        assert np.array_equal(mlds.getRawDictionary(l), z['single_raw%d' % l])
+        assert np.allclose(mlds.getMultiscaleDictionaries()[l], z['single_rep%d' % l], atol=1e-7)
+    assert mlds.withSingletonBases() is mlds
+
+
+def _case_kwargs(z, name):
+    snr = z['case_%s__toleranceSnr' % name]
+    kw = dict(toleranceSnr=[float(v) for v in snr] if int(z['case_%s__snr_is_list' % name]) else float(snr[0]),
+              singletonWeight=float(z['case_%s__singletonWeight' % name]),
+              returnDistributed=bool(int(z['case_%s__returnDistributed' % name])))
+    nb = int(z['case_%s__nbBlocks' % name])
+    kw['nbBlocks'] = 'auto' if nb == -1 else nb
+    return kw
+
+
+def _check_case(hcsc, z, name):
+    x = z['x']
+    kw = _case_kwargs(z, name)
+    coefficients, residual = hcsc.encode(x, **kw)
+    assert len(coefficients) == 3
+    for l, c in enumerate(coefficients):
+        row, col, data = gu.csc_triplets(c)
+        assert np.array_equal(row, z['case_%s__level%d_row' % (name, l)]), 'level %d structure' % l
+        assert np.array_equal(col, z['case_%s__level%d_col' % (name, l)])
+        assert gu.rel_err(data, z['case_%s__level%d_data' % (name, l)]) <= 1e-5
+    exp_res = z['case_%s__residual' % name]
+    assert residual.shape == exp_res.shape and residual.dtype == exp_res.dtype
+    assert float(np.max(np.abs(residual - exp_res))) <= 1e-5
+    if kw['returnDistributed']:
+        assert float(np.max(np.abs(residual))) < float(np.max(np.abs(x)))      # tests/hsc/test_modeling.py:823-869
+    assert float(np.max(np.abs(hcsc.reconstruct(coefficients) - z['case_%s__recon' % name]))) <= 1e-5
+    # encodeFromLevel: resume above level 0 (modeling.py:1645-1654)
+    raw = hcsc.approximator._forwardPhase(x, hcsc.multilevelDict, kw['toleranceSnr'], kw['nbBlocks'], kw['singletonWeight'])
+    cont = hcsc.encodeFromLevel(x, raw[:1], toleranceSnr=kw['toleranceSnr'], nbBlocks=kw['nbBlocks'],
+                                singletonWeight=kw['singletonWeight'], returnDistributed=kw['returnDistributed'])
+    for l, c in enumerate(cont):
+        row, col, data = gu.csc_triplets(c)
+        assert np.array_equal(row, z['case_%s__fromlevel%d_row' % (name, l)])
+        assert np.array_equal(col, z['case_%s__fromlevel%d_col' % (name, l)])
+        assert gu.rel_err(data, z['case_%s__fromlevel%d_data' % (name, l)]) <= 1e-5
+
+
+class _OracleLevelCoder(object):
+    """Stand-in level coder for the CPU tests: same encode() contract, computed by the CPU oracle."""
+
+    def __init__(self, D):
+        self.D = D
+
+    def encode(self, X, **kw):
+        from oracle import hsc_oracle as orc
+        coefficients, residual, _ = orc.cmp_encode(np.asarray(X), self.D, **kw)
+        return coefficients, residual
+
+
+@pytest.mark.parametrize('name', ['a', 'b', 'c'])
+def test_hierarchical_host_logic_with_oracle_level_coder(name, monkeypatch):
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit, HierarchicalConvolutionalSparseCoder
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    monkeypatch.setattr(hcmp, '_level_coder', lambda D: _OracleLevelCoder(D))
+    hcsc = HierarchicalConvolutionalSparseCoder(_mld(), hcmp)
+    _check_case(hcsc, _golden(), name)
+
+
+def test_unsupported_methods_raise():
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    x = _golden()['x']
+    mld = _mld().withSingletonBases()
+    with pytest.raises(NotImplementedError):
+        HierarchicalConvolutionalMatchingPursuit().computeCoefficients(x, mld, toleranceSnr=5.0)      # default 'locomp'
+    with pytest.raises(Exception):
+        HierarchicalConvolutionalMatchingPursuit(method='nope').computeCoefficients(x, mld, toleranceSnr=5.0)
+
+
+def test_distributed_conversion_preserves_nnz():
+    """modeling.py:1556-1594 on a hand-made example."""
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    c0 = scipy.sparse.csc_matrix((6, 2))
+    c1 = scipy.sparse.csc_matrix(np.array([[1., 0, 0, 2.], [0, 0, 0, 0], [0, 3., 4., 0], [0, 0, 0, 0], [0, 0, 5., 0], [0, 0, 0, 0]]))
+    out = HierarchicalConvolutionalMatchingPursuit('cmp').convertToDistributedCoefficients([c0, c1])
+    assert out[0].shape == (6, 2) and out[0].nnz == 2          # the two singleton columns went down a level
+    assert out[1].shape == (6, 4) and out[1].nnz == 3
+    assert out[1][:, :2].nnz == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['a', 'b', 'c'])
+def test_hierarchical_gpu_vs_reference_golden(name):
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, HierarchicalConvolutionalSparseCoder
+    hcsc = HierarchicalConvolutionalSparseCoder(_mld(), HierarchicalConvolutionalMatchingPursuit(method='cmp'))
+    _check_case(hcsc, _golden(), name)

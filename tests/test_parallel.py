@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, encode their shards (with the CPU oracle standing
+in for the GPU engine -- test infrastructure), gather the per-signal results and must reproduce the
+single-process result signal for signal."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_the_batch():
+    from hsc_amd.parallel import shard_bounds
+    for n in (1, 7, 8, 1024, 1031):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _OracleBatch(object):
+    def __init__(self, sequences, D, **kw):
+        from oracle import hsc_oracle as orc
+        self.coefficients, res, self.events, stats, en = [], [], [], [], []
+        for x in sequences:
+            c, r, info = orc.cmp_encode(x, D, **kw)
+            self.coefficients.append(c); res.append(r)
+            self.events.append((info['t'], info['k'], info['c']))
+            stats.append([info['nnz'], info['duplicates'], info['rounds'], 0, info['iterations'], len(info['t']), 0, 0])
+            en.append([info['energy_signal'], info['energy_residual']])
+        self.residuals = np.stack(res); self.stats = np.array(stats, dtype=np.int32); self.energies = np.array(en)
+
+
+def _oracle_encode(sequences, D, **kw):
+    return _OracleBatch(sequences, D, **kw)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import hsc_amd.synth as synth
+    from hsc_amd.parallel import shard_bounds, encode_sharded, broadcast_dictionary
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = synth.make_dictionary(16, 16, seed=5) if rank == 0 else None
+        D, _ = broadcast_dictionary(D, None, src=0)
+        first, last = shard_bounds(7, world, rank)
+        # every rank generates ITS OWN shard from the per-signal streams
+        shard = synth.make_batch(D, 512, first, last - first, kind='planted', nb_atoms=12, seed=5)
+        out = encode_sharded(shard, D, encode_fn=_oracle_encode, nbNonzeroCoefs=12)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'gathered.npz'),
+                     t=np.concatenate([e[0] for e in out['events']]), k=np.concatenate([e[1] for e in out['events']]),
+                     c=np.concatenate([e[2] for e in out['events']]), n=np.array([len(e[0]) for e in out['events']]),
+                     residuals=out['residuals'], stats=out['stats'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), 'gathered.npz'))
+    import hsc_amd.synth as synth
+    D = synth.make_dictionary(16, 16, seed=5)
+    full = synth.make_batch(D, 512, 0, 7, kind='planted', nb_atoms=12, seed=5)
+    ref = _oracle_encode(full, D, nbNonzeroCoefs=12)
+    assert np.array_equal(got['n'], [len(e[0]) for e in ref.events])
+    assert np.array_equal(got['t'], np.concatenate([e[0] for e in ref.events]))
+    assert np.array_equal(got['k'], np.concatenate([e[1] for e in ref.events]))
+    assert np.array_equal(got['c'], np.concatenate([e[2] for e in ref.events]))
+    assert np.array_equal(got['residuals'], ref.residuals)
+    assert got['stats'].shape == (7, 8)

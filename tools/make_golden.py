@@ -12,6 +12,8 @@ Files written:
                                    (reflect padding at both edges) on seeded inputs
   tests/golden/cmp_config.npz   -- BASELINE config 1 (T=4096) and 8 full-size config-2 signals
                                    (T=65536, K=256, W=64, L0=256): outputs + input digests
+  tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
+                                   singleton bases, representations, per-level coefficients, residual
 """
 import os
 import sys
@@ -210,13 +212,94 @@ def gen_config():
     np.savez_compressed(os.path.join(OUT, 'cmp_config.npz'), **out)
 
 
+def make_hsc_dictionaries(rs, dtype=np.float32):
+    """Small 3-level raw dictionaries (no singletons): scales [16,31,61] => widths [16,16,31]."""
+    scales = [16, 31, 61]
+    D0 = rs.standard_normal((8, 16))
+    D0 = (D0 / np.sqrt(np.sum(D0 ** 2, axis=1, keepdims=True))).astype(dtype)
+    dicts = [D0]
+    for (K, W, F) in [(6, 16, 8), (4, 31, 6)]:
+        D = np.zeros((K, W, F))
+        for k in range(K):
+            for _ in range(3):
+                D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+            D[k] /= np.sqrt(np.sum(D[k] ** 2))
+        dicts.append(D.astype(dtype))
+    return dicts, scales
+
+
+def gen_hsc():
+    """Hierarchical encoder (modeling.py:1427-1705, method='cmp') on a small 3-level dictionary."""
+    ref = load_reference()
+    rs = np.random.RandomState(4242)
+    out = {}
+    dicts, scales = make_hsc_dictionaries(rs)
+    mld = ref.dataset.MultilevelDictionary.fromRawDictionaries(dicts, scales)
+    mlds = mld.withSingletonBases()
+    for l, D in enumerate(dicts):
+        out['raw%d' % l] = D
+    out['scales'] = np.array(scales)
+    for l in range(3):
+        out['single_raw%d' % l] = mlds.getRawDictionary(l)
+        out['single_rep%d' % l] = mlds.getMultiscaleDictionaries()[l]
+        out['rep%d' % l] = mld.getMultiscaleDictionaries()[l]
+    out['counts'] = np.array(mlds.counts)
+    out['countsNoSingletons'] = np.array(mlds.countsNoSingletons)
+    # signal: events of all levels through the input-level representations, plus a little noise
+    T = 512
+    x = 0.01 * rs.standard_normal(T)
+    for l in range(3):
+        rep = mld.getMultiscaleDictionaries()[l]
+        for _ in range(6):
+            i = rs.randint(0, rep.shape[0]); t = rs.randint(40, T - 40); c = rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0])
+            s, e, es, ee = synth.centered_span(T, rep.shape[1], t)
+            x[s:e] += c * rep[i][es:ee]
+    x = x.astype(np.float32)
+    out['x'] = x
+    cases = [('a', dict(toleranceSnr=15.0, nbBlocks=1, singletonWeight=0.9)),
+             ('b', dict(toleranceSnr=[20.0, 25.0, 30.0], nbBlocks=4, singletonWeight=0.5, returnDistributed=False)),
+             ('c', dict(toleranceSnr=[10.0, 40.0, 40.0], nbBlocks='auto', singletonWeight=0.95))]
+    names = []
+    for name, kw in cases:
+        hcmp = ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='cmp')
+        hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mld, hcmp)
+        coefficients, residual = hcsc.encode(x, **kw)
+        names.append(name)
+        snr = kw['toleranceSnr']
+        out['case_%s__toleranceSnr' % name] = np.atleast_1d(np.array(snr, dtype=np.float64))
+        out['case_%s__snr_is_list' % name] = np.array(int(isinstance(snr, list)))
+        out['case_%s__nbBlocks' % name] = np.array(-1 if kw['nbBlocks'] == 'auto' else kw['nbBlocks'])
+        out['case_%s__singletonWeight' % name] = np.array(kw['singletonWeight'])
+        out['case_%s__returnDistributed' % name] = np.array(int(kw.get('returnDistributed', True)))
+        out['case_%s__residual' % name] = residual
+        for l, c in enumerate(coefficients):
+            pack_csc('case_%s__level%d' % (name, l), scipy_sparse(c), out)
+        out['case_%s__recon' % name] = hcsc.reconstruct(coefficients)
+        # encodeFromLevel: restart from the level-0 forward result
+        raw = hcmp._forwardPhase(x, hcsc.multilevelDict, kw['toleranceSnr'], kw['nbBlocks'], kw['singletonWeight'])
+        cont = hcsc.encodeFromLevel(x, raw[:1], toleranceSnr=kw['toleranceSnr'], nbBlocks=kw['nbBlocks'],
+                                    singletonWeight=kw['singletonWeight'], returnDistributed=kw.get('returnDistributed', True))
+        for l, c in enumerate(cont):
+            pack_csc('case_%s__fromlevel%d' % (name, l), scipy_sparse(c), out)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'hsc_small.npz'), **out)
+    print('hsc_small.npz: %d cases' % len(names))
+
+
+def scipy_sparse(c):
+    import scipy.sparse
+    return c if scipy.sparse.issparse(c) else scipy.sparse.csc_matrix(c)
+
+
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
         gen_functions()
     if 'config' in which:
         gen_config()
+    if 'hsc' in which:
+        gen_hsc()
