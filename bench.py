@@ -72,7 +72,9 @@ def main():
     ap.add_argument('--L0', type=int, default=256)
     ap.add_argument('--kind', default='planted', choices=['planted', 'noise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI) or 'gloo' (rehearsal)")
     ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the CPU baseline (0 = min(8, cores))')
+    ap.add_argument('--cpu-signals-per-proc', type=int, default=4, help='signals each CPU process encodes (~3 s each)')
     ap.add_argument('--profile-steps', type=int, default=3, help='extra untimed steps used for per-kernel HIP-event timing')
     args = ap.parse_args()
 
@@ -93,7 +95,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nproc = args.cpu_procs or min(8, os.cpu_count() or 1)
-        cpu = cpu_baseline(cfg, nproc, 1)
+        cpu = cpu_baseline(cfg, nproc, args.cpu_signals_per_proc)
 
     import numpy as np
     import torch
@@ -103,10 +105,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU path to fall back to')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # one rank per GPU; wraps only in 1-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)     # RCCL
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)     # RCCL
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic inputs: this rank's shard of the (weakly scaled) batch, resident in HBM
     D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2)
@@ -116,7 +122,7 @@ def main():
     del x_host
 
     stream = torch.cuda.Stream(device=dev)
-    eng = _native.Engine(local_rank)
+    eng = _native.Engine(dev_index)
     eng.set_stream(stream.cuda_stream)
     eng.set_dictionary(D)
     params = _native.make_params(nbNonzeroCoefs=cfg['L0'], nbBlocks=1, minCoefficients=1e-16,
@@ -156,8 +162,9 @@ def main():
         kms += eng.last_kernel_ms().astype(np.float64)
     kms /= max(1, args.profile_steps)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    t_sel = torch.tensor([float(nsel_local)], dtype=torch.float64, device=dev)
+    cdev = dev if args.backend == 'nccl' else torch.device('cpu')
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    t_sel = torch.tensor([float(nsel_local)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(t_sel, op=dist.ReduceOp.SUM)
@@ -172,6 +179,16 @@ def main():
                 ('iterate (greedy loop re-correlation, modeling.py:1018-1051)', flop_loop, kms[2])]
         dom = max(kern, key=lambda k: k[2])
         achieved = dom[1] / (dom[2] * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs, gfx950 correction applied by tools/parse_pmc.py); null if not collected
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
+            key = 'corr_init_mfma_kernel' if dom is kern[0] else 'iterate_kernel'
+            if cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma'):
+                traffic = pmc[key]['hbm_bytes_per_launch']
+        except Exception:
+            traffic = None
         out = {
             'metric': 'atom-selections/sec (+ residual-energy match) on 1-D CSC',
             'value': nsel_total * args.steps / elapsed_max,
@@ -186,7 +203,7 @@ def main():
                        'selections_per_step': nsel_total, 'variant': variant,
                        'stop_reasons': {_native.STOP_NAMES[i]: int(n) for i, n in enumerate(stops) if n}},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'kernel': dom[0],
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch (PMC)', 'kernel': dom[0],
                          'kernel_ms': float(dom[2]),
                          'all_kernels': [{'kernel': k[0], 'algorithmic_tflop': k[1] / 1e12, 'ms': float(k[2]),
                                           'tflops': (k[1] / (k[2] * 1e-3) / 1e12) if k[2] > 0 else None} for k in kern],
