@@ -39,7 +39,7 @@ struct hscmp_ctx {
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
     int* d_slot_t = nullptr; int* d_slot_k = nullptr; double* d_slot_a = nullptr;
     int* d_sel_t = nullptr; int* d_sel_k = nullptr; void* d_sel_c = nullptr;
-    int* d_stats = nullptr; void* d_energy = nullptr;
+    int* d_stats = nullptr; void* d_energy = nullptr; unsigned long long* d_edge = nullptr;
     DevParams P{};
     hscmp_params last{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -100,7 +100,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 static void free_all(hscmp_ctx* c)
 {
     void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
-                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy};
+                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -218,6 +218,7 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_sel_c, &ctx->caps[12], B * 2 * ms * es},
         {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
         {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
+        {(void**)&ctx->d_edge, &ctx->caps[15], B * 2 * sizeof(unsigned long long)},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -239,14 +240,15 @@ template <typename R> static State<R> make_state(hscmp_ctx* c)
     S.ev_t = c->d_ev_t; S.ev_k = c->d_ev_k; S.ev_c = (R*)c->d_ev_c;
     S.slot_t = c->d_slot_t; S.slot_k = c->d_slot_k; S.slot_a = c->d_slot_a;
     S.sel_t = c->d_sel_t; S.sel_k = c->d_sel_k; S.sel_c = (R*)c->d_sel_c;
-    S.stats = c->d_stats; S.energy = (R*)c->d_energy;
+    S.stats = c->d_stats; S.energy = (R*)c->d_energy; S.edge = c->d_edge;
     return S;
 }
 
-static bool use_mfma(const hscmp_ctx* ctx)
+static bool use_mfma(const hscmp_ctx* ctx, int T)
 {
     if (getenv("HSCMP_FORCE_GENERIC")) return false;
-    return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr;
+    // the score-only MFMA path assumes single-bounce reflection at the edges (T >= 3W-2)
+    return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
 template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams& P0)
@@ -267,7 +269,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     bool mf = false;
-    if (sizeof(R) == 4 && use_mfma(ctx)) {
+    if (sizeof(R) == 4 && use_mfma(ctx, P.T)) {
         int rc = mfma_launch_corr_init(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mf = true;
     }
@@ -278,7 +280,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     bool mfi = false;
-    if (sizeof(R) == 4 && use_mfma(ctx)) {
+    if (sizeof(R) == 4 && use_mfma(ctx, P.T)) {
         int rc = mfma_launch_iterate(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mfi = true;
     }
@@ -331,7 +333,7 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
     DevParams P = ctx->P;
     P.max_rounds = max_rounds;
     bool mfi = false;
-    if (ctx->dtype == HSCMP_F32 && use_mfma(ctx)) {
+    if (ctx->dtype == HSCMP_F32 && use_mfma(ctx, P.T)) {
         State<float> S = make_state<float>(ctx);
         if (mfma_launch_iterate(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
     }

@@ -64,6 +64,7 @@ template <typename R> struct State {
     int* sel_t; int* sel_k; R* sel_c;         // [B][2*maxsel]  (two halves: raw / ordered)
     int* stats;         // [B][ST_COUNT]
     R* energy;          // [B][2]: signal, residual
+    unsigned long long* edge;   // [B][2]: edge rows re-correlated at least once (score-only policies)
 };
 
 __device__ __forceinline__ float rabs(float v) { return fabsf(v); }

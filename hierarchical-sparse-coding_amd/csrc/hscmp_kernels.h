@@ -44,6 +44,8 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(DevParams P, State<R>
         S.energy[2 * b + 1] = p;
         int* st = S.stats + (int64_t)b * ST_COUNT;
         for (int i = 0; i < ST_COUNT; ++i) st[i] = 0;
+        S.edge[2 * b + 0] = 0ull;
+        S.edge[2 * b + 1] = 0ull;
     }
 }
 
@@ -89,11 +91,11 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
 // ------------------------------------------------------------------------------------------------
 // shared state of the greedy loop
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MAXSEG, bool WITH_PART = true> struct IterSharedT {
+template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> struct IterSharedT {
     R seg_score[MAXSEG];
-    R seg_c[MAXSEG];
     int seg_t[MAXSEG];
-    int seg_k[MAXSEG];
+    R seg_c[WITH_CK ? MAXSEG : 1];            // coefficient / atom of the segment maximum (not kept by
+    int seg_k[WITH_CK ? MAXSEG : 1];          // score-only policies, which resolve them on demand)
     R rseg[MAXSEG];           // max |residual| per segment (toleranceResidualScale only)
     R part_s[WITH_PART ? kThreads : 1];       // GenericRecorr's cross-group merge buffers
     R part_c[WITH_PART ? kThreads : 1];
@@ -116,30 +118,31 @@ template <typename R> struct Sig {   // per-signal views
     int* sel_t; int* sel_k; R* sel_c;
 };
 
-// arg-max of the per-position best over positions [t0,t1) by one wave; result in all lanes
-template <typename R>
+// arg-max of the per-position best over positions [t0,t1) by one wave; result in all lanes.
+// SO (score-only policy): G.bc[t] already IS the score max_k |c[t,k]*w_k|.
+template <bool SO, typename R>
 __device__ __forceinline__ Cand<R> wave_range_argmax(const Sig<R>& G, const R* w, int t0, int t1, int lane)
 {
     Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
     for (int t = t0 + lane; t < t1; t += 64) {
-        const R s = score_of(G.bc[t], G.bk[t], w);
+        R s;
+        if constexpr (SO) s = G.bc[t]; else s = score_of(G.bc[t], G.bk[t], w);
         if (s > best.s) { best.s = s; best.i = t; }
     }
     return wave_argmax(best);
 }
 
-template <typename R, typename SH>
+template <bool SO, typename R, typename SH>
 __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
 {
     const int t0 = (sg << P.seg_shift);
     const int t1 = min(P.T, t0 + P.seg);
-    Cand<R> win = wave_range_argmax(G, w, t0, t1, lane);
+    Cand<R> win = wave_range_argmax<SO>(G, w, t0, t1, lane);
     if (lane == 0) {
         if (win.i == INT_MAX) { win.i = t0; win.s = (R)0; }
         sh.seg_score[sg] = win.s;
         sh.seg_t[sg] = win.i;
-        sh.seg_c[sg] = G.bc[win.i];
-        sh.seg_k[sg] = G.bk[win.i];
+        if constexpr (!SO) { sh.seg_c[sg] = G.bc[win.i]; sh.seg_k[sg] = G.bk[win.i]; }
     }
 }
 
@@ -206,8 +209,12 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
 template <typename R> struct GenericRecorr {
     static constexpr int kMaxSegments = kMaxSeg;
     static constexpr bool kFused = false;               // uses the step-by-step atom body of iterate_kernel
+    static constexpr bool kScoreOnly = false;           // keeps (coefficient, atom) per position
     using Shared = IterSharedT<R, kMaxSeg>;
     struct Args {};                                     // no extra kernel arguments
+    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
+                                                        int, int, int&, R&) {}
     static size_t extra_lds_bytes(const DevParams&) { return 0; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
     template <typename SH>
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     Recorr::prologue(P, S, A, plds);
 
     // ---- prologue: segment maxima of the per-position best (and of |residual|)
-    for (int sg = wv; sg < P.nseg; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
+    for (int sg = wv; sg < P.nseg; sg += kWaves) scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
     if (P.has_scale) for (int sg = wv; sg < P.nseg; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
     if (tid == 0) {
         sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
@@ -323,8 +330,13 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 }
                 c = wave_argmax(c);
                 const int sg = c.i;
-                p_sel = sh.seg_t[sg]; k_sel = sh.seg_k[sg]; c_sel = sh.seg_c[sg];
-                nsel = (has_thres && !(fabs((double)c_sel) > thres)) ? 0 : 1;     // :974
+                p_sel = sh.seg_t[sg];
+                if constexpr (Recorr::kScoreOnly) {
+                    nsel = 1;              // (k, c) and the null test (:974) are resolved inside apply_atom
+                } else {
+                    k_sel = sh.seg_k[sg]; c_sel = sh.seg_c[sg];
+                    nsel = (has_thres && !(fabs((double)c_sel) > thres)) ? 0 : 1;     // :974
+                }
             } else {
                 Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
                 for (int i = tid; i < P.nseg; i += kThreads) {
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                     Cand<R> m = sh.cred[0];
                     for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
                     const int sg = m.i;
-                    const R cc = sh.seg_c[sg];
+                    const R cc = sh.seg_c[sg];          // (non-fused policies keep coefficient / atom per segment)
                     sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
                     sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
                 }
@@ -356,14 +368,16 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 const int lo = w0 < 0 ? 0 : w0;
                 const int hi = min(T, w0 + P.bs);
                 Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
-                if (lo < hi) win = wave_range_argmax(G, wts, lo, hi, lane);
-                if (lane == 0) {
-                    bool valid = (lo < hi) && win.i != INT_MAX;                  // :940-942 range test
-                    if (valid && win.s == (R)0 && w0 < 0) valid = false;         // arg-max on a leading padded row
-                    raw_t[j] = valid ? win.i : -1;
-                    raw_k[j] = valid ? G.bk[win.i] : 0;
-                    raw_c[j] = valid ? G.bc[win.i] : (R)0;
+                if (lo < hi) win = wave_range_argmax<Recorr::kScoreOnly>(G, wts, lo, hi, lane);
+                bool valid = (lo < hi) && win.i != INT_MAX;                      // :940-942 range test
+                if (valid && win.s == (R)0 && w0 < 0) valid = false;             // arg-max on a leading padded row
+                int wk = 0;
+                R wc = (R)0;
+                if (valid) {                                                     // wave-uniform
+                    if constexpr (Recorr::kScoreOnly) Recorr::resolve_wave(P, S, G, A, plds, win.i, lane, wk, wc);
+                    else { wk = G.bk[win.i]; wc = G.bc[win.i]; }
                 }
+                if (lane == 0) { raw_t[j] = valid ? win.i : -1; raw_k[j] = wk; raw_c[j] = wc; }
             }
             __syncthreads();
             // :946-948 drop null coefficients (and invalid blocks): raw -> ord
@@ -424,8 +438,9 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if (!P.blocked) { p = p_sel; k = k_sel; c = c_sel; }
             else { p = ord_t[ai]; k = ord_k[ai]; c = ord_c[ai]; }
             if constexpr (Recorr::kFused) {
-                // policy-owned atom body: one batch of global loads, three barriers (hscmp_mfma.h)
-                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c)) { fused_stop = true; break; }
+                // policy-owned atom body: one batch of global loads, LDS-only barriers (hscmp_mfma.h);
+                // in blocked mode (k, c) were resolved at selection time
+                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0)) { fused_stop = true; break; }
                 continue;
             }
 
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             {
                 const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
                 const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
-                for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment(P, G, wts, sh, sg, lane);
+                for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
             }
 
             // ---- :1122-1142 fast stop rules
@@ -539,6 +554,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     }
 
     __syncthreads();
+    Recorr::epilogue(P, S, A, plds);
     if (tid == 0) {
         stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;
         stats[ST_ITERS] = sh.iters; stats[ST_EVENTS] = sh.nev; stats[ST_SLOTS] = sh.nslots; stats[ST_OFFSET] = sh.offset;

@@ -50,7 +50,7 @@ inline int mfma_chunks(int W) { return (W + 7) / 8; }
 
 inline bool mfma_supported(int K, int W, int F)
 {
-    if (F != 1) return false;
+    if (F != 1) return false;   // (per launch, T >= 3W-2 is required as well: see mfma_shape_ok)
     const size_t bytes = (size_t)mfma_groups(K) * mfma_chunks(W) * 64 * 4 * sizeof(float);
     return bytes <= kMfmaMaxDictBytes && W <= 128;
 }
@@ -89,29 +89,45 @@ __device__ __forceinline__ int swap_halves_i(int v, int h)
 }
 __device__ __forceinline__ float swap_halves_f(float v, int h) { return __int_as_float(swap_halves_i(__float_as_int(v), h)); }
 
+// ------------------------------------------------------------------------------------------------
+// One 32-position tile against all atom groups: per-position best SCORE max_k |c[t,k] * w_k|.
+//   dimg : LDS dictionary image;  win : LDS floats, win[j + kk + 2s] is the B operand (see above)
+//   wts  : LDS weights [32*G] (HAS_W) ;  result valid in every lane (position = lane & 31)
+//
+// Score-only state: the fp32 MFMA shares the FP32 datapath with the vector ALU (measured: VALU
+// work next to the MFMA chain does not overlap, it adds), so the per-element cost of the arg-max
+// is what limits the kernel.  Keeping only the score needs one v_max3_f32 per TWO accumulator
+// elements (|.| is a free source modifier) instead of compare + two selects per element; the atom
+// index and the signed coefficient of a position are recomputed ("resolved") from one row of
+// K*W multiply-adds only when that position is actually selected.
+//
+// S4C > 0: compile-time chunk count -- B operands live in registers, A operands and accumulators
+// are double buffered: group g+1's A fragments are fetched while group g's MFMA chain runs, and
+// the reduction of group g-1 is interleaved between the MFMA issues of group g.
+// S4C == 0: runtime chunk count (any W), simple loop.
+// ------------------------------------------------------------------------------------------------
 template <bool HAS_W>
-__device__ __forceinline__ void mfma_reduce_elem(float v, int k, const float* __restrict__ wts, float& bs, float& bc, int& bk)
+__device__ __forceinline__ void mfma_reduce_pair(float v0, float v1, int k0, int k1, const float* __restrict__ wts, float& bs)
 {
-#ifdef HSCMP_DBG_NO_REDUCE   // diagnostic build: keep the accumulator live, skip the arg-max
-    asm volatile("" :: "v"(v));
-    (void)k; (void)wts; (void)bs; (void)bc; (void)bk;
+#ifdef HSCMP_DBG_NO_REDUCE   // diagnostic build: keep the accumulator live, skip the reduction
+    asm volatile("" :: "v"(v0), "v"(v1));
+    (void)k0; (void)k1; (void)wts; (void)bs;
 #else
-    float s;
-    if (HAS_W) { const float sw = v * wts[k]; s = fabsf(sw); } else s = fabsf(v);
-    if (s > bs) { bs = s; bc = v; bk = k; }    // ascending k, strict >: the first k wins ties
+    if (HAS_W) { v0 = v0 * wts[k0]; v1 = v1 * wts[k1]; }      // modeling.py:906, one rounded product each
+    bs = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), bs);              // v_max3_f32 |v0|, |v1|, bs
 #endif
 }
 
 template <int S4C, bool HAS_W>
-__device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, const float* __restrict__ win,
-                                               const float* __restrict__ wts, int G, int S4rt, int lane,
-                                               float& out_c, int& out_k)
+__device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg, const float* __restrict__ win,
+                                                 const float* __restrict__ wts, int G, int S4rt, int lane)
 {
     const int j = lane & 31, h = lane >> 5;
     const float* wb = win + j + h;
-    float bs = -1.0f, bc = 0.0f;
-    int bk = 0;
+    float bs = 0.0f;                           // scores are >= 0
     const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
+    // atom of accumulator element r: 32g + 4h + (r&3) + 8(r>>2); pair (2e, 2e+1) shares one v_max3
+    auto katom = [&](int kbase, int r) { return kbase + (r & 3) + 8 * (r >> 2); };
 
     if constexpr (S4C > 0) {
         constexpr int NM = 4 * S4C;            // MFMAs per atom group
@@ -130,14 +146,14 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
             for (int s4 = 0; s4 < S4C; ++s4) a[s4] = dv[(g * S4C + s4) * 64];
 #endif
         };
-        // MFMA chain of one group into `acc`; with PREV, the 16 arg-max steps of the previous
-        // group's accumulator `accp` are spread between the MFMA issues
         auto run_first = [&](const f32x4 (&a)[S4C], f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2][m & 3], bop[m], acc, 0, 0, 0);
         };
+        // MFMA chain of one group into `acc`; the 8 reduction steps of the previous group's
+        // accumulator `accp` are spread between the MFMA issues
         auto run_next = [&](const f32x4 (&a)[S4C], f32x16& acc, const f32x16& accp, int kbasep) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -145,15 +161,16 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
             for (int m = 0; m < NM; ++m) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2][m & 3], bop[m], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = (m * 16) / NM; r < ((m + 1) * 16) / NM; ++r)
-                    mfma_reduce_elem<HAS_W>(accp[r], kbasep + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
+                for (int e = (m * 8) / NM; e < ((m + 1) * 8) / NM; ++e)
+                    mfma_reduce_pair<HAS_W>(accp[2 * e], accp[2 * e + 1], katom(kbasep, 2 * e), katom(kbasep, 2 * e + 1), wts, bs);
             }
         };
         auto reduce_all = [&](const f32x16& acc, int kbase) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mfma_reduce_elem<HAS_W>(acc[r], kbase + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
+            for (int e = 0; e < 8; ++e)
+                mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(kbase, 2 * e), katom(kbase, 2 * e + 1), wts, bs);
         };
-        const int kb0 = 4 * h;                 // atom of accumulator element r: 32g + 4h + (r&3) + 8(r>>2)
+        const int kb0 = 4 * h;
 
         load_a(a0, 0);
         if (G > 1) load_a(a1, 1);
@@ -187,17 +204,12 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
             }
             const int kbase = 32 * g + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mfma_reduce_elem<HAS_W>(acc[r], kbase + (r & 3) + 8 * (r >> 2), wts, bs, bc, bk);
+            for (int e = 0; e < 8; ++e)
+                mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(kbase, 2 * e), katom(kbase, 2 * e + 1), wts, bs);
         }
     }
-    // merge the two half-waves (same position, interleaved atom sets): larger score, then lower k
-    // v_permlane32_swap (VALU speed): element [h] of the result is the value held by half-wave h
-    const float os = swap_halves_f(bs, h);
-    const float oc = swap_halves_f(bc, h);
-    const int ok = swap_halves_i(bk, h);
-    if (os > bs || (os == bs && ok < bk)) { bc = oc; bk = ok; }
-    out_c = bc;
-    out_k = bk;
+    // the two half-waves hold the same position with interleaved atom sets
+    return fmaxf(bs, swap_halves_f(bs, h));
 }
 
 __device__ __forceinline__ void lds_copy_f32(float* dst, const float* __restrict__ src, int n)
@@ -279,13 +291,9 @@ __global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, S
         const int npos = min(kMfmaChunk, T - c0);
         const int ntiles = (npos + 31) / 32;
         for (int q = wv; q < ntiles; q += kWaves) {
-            float c; int k;
-            mfma_tile_best<S4C, HAS_W>(dimg, xs + 32 * q, wts, G, S4, lane, c, k);
+            const float sc = mfma_tile_score<S4C, HAS_W>(dimg, xs + 32 * q, wts, G, S4, lane);
             const int t = c0 + 32 * q + lane;
-            if (lane < 32 && t < T) {
-                S.best_c[(int64_t)b * T + t] = c;
-                S.best_k[(int64_t)b * T + t] = k;
-            }
+            if (lane < 32 && t < T) S.best_c[(int64_t)b * T + t] = sc;      // score-only state (see mfma_tile_score)
         }
         __syncthreads();                                // all tiles read xs before it is overwritten
     }
@@ -331,21 +339,69 @@ __device__ __forceinline__ int dimg_index(int k, int w, int S4)
     return (((k >> 5) * S4 + (w >> 3)) * 64 + (k & 31) + 32 * (w & 1)) * 4 + ((w >> 1) & 3);
 }
 
+// D[k][.] . rwin[.] as the pinned sequential fma chain (taps ascending), D read from the LDS image:
+// for chunk s4 the two 16-byte words of lanes (k&31) and (k&31)+32 hold taps 8*s4 + {0,2,4,6} and
+// 8*s4 + {1,3,5,7}.  fma(r, d, acc) == fma(d, r, acc): bit-identical to the MFMA chain.
+template <int S4C>
+__device__ __forceinline__ float resolve_chain(const float* __restrict__ dimg, const float* __restrict__ rwin, int k, int S4rt)
+{
+    const int S4 = S4C > 0 ? S4C : S4rt;
+    const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + ((k >> 5) * S4) * 64 + (k & 31);
+    const f32x4* rw = reinterpret_cast<const f32x4*>(rwin);
+    float acc = 0.0f;
+#pragma unroll
+    for (int s4 = 0; s4 < (S4C > 0 ? S4C : S4); ++s4) {
+        const f32x4 a0 = dv[s4 * 64], a1 = dv[s4 * 64 + 32];
+        const f32x4 r0 = rw[2 * s4], r1 = rw[2 * s4 + 1];
+        acc = fmaf(r0[0], a0[0], acc);
+        acc = fmaf(r0[1], a1[0], acc);
+        acc = fmaf(r0[2], a0[1], acc);
+        acc = fmaf(r0[3], a1[1], acc);
+        acc = fmaf(r1[0], a0[2], acc);
+        acc = fmaf(r1[1], a1[2], acc);
+        acc = fmaf(r1[2], a0[3], acc);
+        acc = fmaf(r1[3], a1[3], acc);
+    }
+    return acc;
+}
+
+// Residual sample at global index g as seen by the window of position p.  Inside the signal: the
+// sample.  Outside: the initial table is ZERO padded (modeling.py:159-164) but every local update
+// REFLECT pads (modeling.py:1046), so a row that has been re-correlated at least once (edge bit set)
+// sees r reflected about 0 / T-1, an untouched one sees 0.  (T >= 3W-2 on this path: one bounce.)
+__device__ __forceinline__ float edge_window_value(const float* __restrict__ r, int T, int g, int p, const unsigned long long* edge)
+{
+    if (g >= 0 && g < T) return r[g];
+    if (g < 0) return ((edge[0] >> p) & 1ull) ? r[-g] : 0.0f;
+    return ((edge[1] >> (T - 1 - p)) & 1ull) ? r[2 * (T - 1) - g] : 0.0f;
+}
+
+__device__ __forceinline__ unsigned long long bit_range(int a, int b)     // bits a..b (0 <= a <= b <= 63)
+{
+    const unsigned long long hi = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+    return hi & ~((1ull << a) - 1ull);
+}
+
 template <int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
-    static constexpr int kBook = 192;       // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
-    using Shared = IterSharedT<float, kMfmaMaxSeg, false>;
+    static constexpr bool kScoreOnly = true;    // best_c[t] holds max_k |c[t,k]*w_k|; (k, c) resolved on selection
+    static constexpr int kBook = 192;           // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
+    using Shared = IterSharedT<float, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgs;
 
-    struct Layout { float* dimg; float* wts; float* win; float* esq; float* sbc; int* sbk; unsigned* bloom; int nwin, wp, nsbmax; };
+    struct Layout {
+        float* dimg; float* wts; float* win; float* esq; float* sbs; unsigned* bloom;
+        float* rwin; float* rwin_w; unsigned long long* edge;
+        int nwin, wp, nsbmax;
+    };
 
     static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + 31) / 32) * 32 + 8 * S4 + 32; }
     static __host__ __device__ int segbuf_len(int W, int seg) { return ((2 * W - 2) / seg + 2) * seg; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A)
     {
         return ((size_t)A.G * A.S4 * 256 + (HAS_W ? 32 * A.G : 0) + window_floats(P.W, A.S4) + 2 * 8 * A.S4 +
-                2 * (size_t)segbuf_len(P.W, P.seg) + kBloomWords) * sizeof(float);
+                (size_t)segbuf_len(P.W, P.seg) + kBloomWords + 8 * A.S4 + kWaves * 8 * A.S4 + 4) * sizeof(float);
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
@@ -358,9 +414,11 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         L.nsbmax = segbuf_len(P.W, P.seg);
         L.win = L.wts + (HAS_W ? 32 * A.G : 0);
         L.esq = L.win + L.nwin;
-        L.sbc = L.esq + 2 * L.wp;
-        L.sbk = reinterpret_cast<int*>(L.sbc + L.nsbmax);
-        L.bloom = reinterpret_cast<unsigned*>(L.sbk + L.nsbmax);
+        L.sbs = L.esq + 2 * L.wp;
+        L.bloom = reinterpret_cast<unsigned*>(L.sbs + L.nsbmax);
+        L.rwin = reinterpret_cast<float*>(L.bloom + kBloomWords);
+        L.rwin_w = L.rwin + L.wp;
+        L.edge = reinterpret_cast<unsigned long long*>(L.rwin_w + kWaves * L.wp);
         return L;
     }
 
@@ -368,13 +426,15 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
     {
         const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
+        const int b = blockIdx.x;
         lds_copy_f32(L.dimg, A.dimg, A.G * S4 * 256);
         if (HAS_W) for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : 0.0f;
         for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = 0.0f;   // the tail behind the span stays zero
         for (int i = threadIdx.x; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
+        for (int i = threadIdx.x; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = 0.0f;   // padded taps stay zero
+        if (threadIdx.x < 2) L.edge[threadIdx.x] = S.edge[2 * b + threadIdx.x];
         __syncthreads();
         // resumed launch: re-enter the (t,k) pairs selected so far
-        const int b = blockIdx.x;
         const int nslots = S.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
         const int* st = S.slot_t + (int64_t)b * P.cap;
         const int* sk = S.slot_k + (int64_t)b * P.cap;
@@ -385,31 +445,49 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         // visibility: the caller's next __syncthreads()
     }
 
-    // step-by-step form (used by the non-fused atom body; kept so that both bodies stay buildable)
-    template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams& P, const State<float>&, const Sig<float>& Gs,
-                                               SH&, const Args& A, char* lds, int p)
+    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<float>& S, const Args& A, char* lds)
     {
-        const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        const int S4 = S4C > 0 ? S4C : A.S4;
         const Layout L = layout(P, A, lds);
-        const int nrows = 2 * W - 1, ntiles = (nrows + 31) / 32, span = 3 * W - 2;
-        const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);
-        const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend, nslice = eidx - sidx + 1;
-        for (int i = tid; i < span; i += kThreads) L.win[i] = Gs.r[reflect_index(tstart + i, sidx, nslice)];
-        __syncthreads();
-        for (int q = wv; q < ntiles; q += kWaves) {
-            float c; int k;
-            mfma_tile_best<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane, c, k);
-            const int row = 32 * q + lane, t = p - (W - 1) + row;
-            if (lane < 32 && row < nrows && t >= 0 && t < T) { Gs.bc[t] = c; Gs.bk[t] = k; }
-        }
+        if (threadIdx.x < 2) S.edge[2 * blockIdx.x + threadIdx.x] = L.edge[threadIdx.x];
     }
 
-    // One applied atom (p, k, c): modeling.py:1106-1142.  Returns true when the atom loop must stop.
+    // never reached: iterate_kernel hands the whole atom body to apply_atom() when kFused
+    template <typename SH>
+    static __device__ __forceinline__ void run(const DevParams&, const State<float>&, const Sig<float>&, SH&, const Args&, char*, int) {}
+
+    // (k, c) of position t by ONE wave (blocked selection, modeling.py:935-946): the window goes to
+    // this wave's private LDS strip, lanes stride over the atoms, first k wins ties.
+    static __device__ __forceinline__ void resolve_wave(const DevParams& P, const State<float>&, const Sig<float>& Gs,
+                                                        const Args& A, char* lds, int t, int lane, int& k_out, float& c_out)
+    {
+        const Layout L = layout(P, A, lds);
+        const int S4 = S4C > 0 ? S4C : A.S4;
+        float* rw = L.rwin_w + (threadIdx.x >> 6) * L.wp;
+        __builtin_amdgcn_wave_barrier();
+        for (int w = lane; w < P.W; w += 64) rw[w] = edge_window_value(Gs.r, P.T, t - P.off + w, t, L.edge);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
+        float bc = 0.0f;
+        for (int k = lane; k < P.K; k += 64) {
+            const float acc = resolve_chain<S4C>(L.dimg, rw, k, S4);
+            float sc;
+            if (HAS_W) { const float sw = acc * L.wts[k]; sc = fabsf(sw); } else sc = fabsf(acc);
+            if (sc > best.s) { best.s = sc; best.i = k; bc = acc; }
+        }
+        best = wave_argmax(best);
+        k_out = best.i;
+        c_out = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc), best.i & 63));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // One applied atom at position p: modeling.py:1106-1142.  resolved: (k, c) already known (blocked
+    // selection); otherwise they are resolved here and the null test of :974 is applied.
+    // Returns true when the atom loop must stop.
     template <typename SH>
     static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<float>& S, const Sig<float>& Gs,
-                                                      SH& sh, const Args& A, char* lds, int p, int k, float c)
+                                                      SH& sh, const Args& A, char* lds, int p, int k, float c, bool resolved)
     {
         (void)S;
         const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -446,18 +524,54 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
                 rv[u] = Gs.r[rm[u]];
             }
         }
-        float oc[2]; int ok[2];
+        float os[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * kThreads;
-            oc[u] = 0.0f; ok[u] = 0;
-            if (i < nsb) { oc[u] = Gs.bc[segbase + i]; ok[u] = Gs.bk[segbase + i]; }
+            os[u] = 0.0f;
+            if (i < nsb) os[u] = Gs.bc[segbase + i];            // old scores of the touched segments
         }
+        if (!resolved) {
+            if (tid < W) L.rwin[tid] = edge_window_value(Gs.r, T, p - P.off + tid, p, L.edge);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kThreads;
+            if (i < nsb) L.sbs[i] = os[u];
+        }
+
+        // ---- resolve (k, c) of the selected position (:970) ------------------------------------
+        if (!resolved) {
+            lds_barrier();                                      // Bx: the position's window is in LDS
+            Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
+            float bc = 0.0f;
+            for (int kk = tid; kk < P.K; kk += kThreads) {
+                const float acc = resolve_chain<S4C>(L.dimg, L.rwin, kk, S4);
+                float sc;
+                if (HAS_W) { const float sw = acc * L.wts[kk]; sc = fabsf(sw); } else sc = fabsf(acc);
+                if (sc > best.s) { best.s = sc; best.i = kk; bc = acc; }
+            }
+            const Cand<float> wbest = wave_argmax(best);
+            if (best.i == wbest.i && wbest.i != INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = bc; }   // the owner lane
+            if (lane == 0 && wbest.i == INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = 0.0f; }
+            lds_barrier();                                      // By
+            Cand<float> m = sh.cred[0];
+            c = sh.red[0];
+#pragma unroll
+            for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) { m = sh.cred[q]; c = sh.red[q]; }
+            k = m.i;
+            if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
+                if (tid == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
+                __syncthreads();
+                return true;
+            }
+        }
+
         // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
         const unsigned hb = bloom_hash(p, k);
         const bool maybe_dup = ((L.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;      // uniform
         if (maybe_dup) {
-            __syncthreads();                                    // drains thread 0's deferred slot stores
+            __syncthreads();                                    // drains the bookkeeper's deferred slot stores
             const int nslots = sh.nslots;
             for (int i = tid; i < nslots; i += kThreads)
                 if (Gs.slot_t[i] == p && Gs.slot_k[i] == k) sh.found = i;      // at most one match
@@ -484,14 +598,13 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
                 }
                 L.win[i] = v;
             }
-            if (i < nsb) { L.sbc[i] = oc[u]; L.sbk[i] = ok[u]; }
         }
-        HSCMP_STAMP(0);                                         // phase A + update, up to B1
+        HSCMP_STAMP(0);                                         // phase A + resolve + update, up to B1
         if (P.has_scale) {                                      // toleranceResidualScale: max|r| of touched segments
             __syncthreads();                                    // B1 (+ residual stores visible to the scan)
             for (int sg = (s >> P.seg_shift) + wv; sg <= ((e - 1) >> P.seg_shift); sg += kWaves) rscan_segment(P, Gs, sh, sg, lane);
         } else {
-            lds_barrier();                                      // B1: window, squares, segment buffers in LDS
+            lds_barrier();                                      // B1: window, squares, segment buffer in LDS
         }
         HSCMP_STAMP(1);                                         // B1
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
@@ -506,20 +619,19 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             }
             if (lane == 0) { sh.red[wv] = pb; sh.red[kWaves + wv] = pa; }
         }
-
         HSCMP_STAMP(2);                                         // energy partials
+
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
         for (int q = wv; q < ntiles; q += kWaves) {
-            float bc; int bk;
-            mfma_tile_best<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane, bc, bk);
+            const float sc = mfma_tile_score<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane);
             const int row = 32 * q + lane, t = p - (W - 1) + row;
             if (lane < 32 && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
-                Gs.bc[t] = bc; Gs.bk[t] = bk;
-                L.sbc[t - segbase] = bc; L.sbk[t - segbase] = bk;
+                Gs.bc[t] = sc;
+                L.sbs[t - segbase] = sc;
             }
         }
         HSCMP_STAMP(3);                                         // MFMA tile(s) of this wave
-        lds_barrier();                                          // B4: per-row results in the segment buffers
+        lds_barrier();                                          // B4: per-row scores in the segment buffer
         HSCMP_STAMP(4);                                         // B4
 
         // ---- maxima of the touched segments, out of LDS
@@ -527,18 +639,13 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             const int t0 = (sg << P.seg_shift), t1 = min(T, t0 + P.seg);
             Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
             for (int t = t0 + lane; t < t1; t += 64) {
-                const float cc = L.sbc[t - segbase];
-                float sc;
-                if (HAS_W) { const float sw = cc * L.wts[L.sbk[t - segbase]]; sc = fabsf(sw); } else sc = fabsf(cc);
+                const float sc = L.sbs[t - segbase];
                 if (sc > best.s) { best.s = sc; best.i = t; }
             }
             best = wave_argmax(best);
-            if (lane == 0) {
-                sh.seg_score[sg] = best.s; sh.seg_t[sg] = best.i;
-                sh.seg_c[sg] = L.sbc[best.i - segbase]; sh.seg_k[sg] = L.sbk[best.i - segbase];
-            }
+            if (lane == 0) { sh.seg_score[sg] = best.s; sh.seg_t[sg] = best.i; }
         }
-        // ---- bookkeeping and the fast stop rules (:1106-1142) on thread 0
+        // ---- bookkeeping and the fast stop rules (:1106-1142) on the bookkeeping thread
         int si = -1, ev = 0;
         bool new_slot = false;
         double acc_old = 0.0;
@@ -556,6 +663,10 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             if (si < 0) { new_slot = true; si = sh.nslots++; L.bloom[hb >> 5] |= 1u << (hb & 31); }
             ev = sh.nev++;
             sh.iters += 1;
+            // rows lo..hi now carry reflect-padded values (see edge_window_value)
+            if (lo < P.off) L.edge[0] |= bit_range(lo, min(hi, P.off - 1));
+            const int rt0 = T - (W - 1 - P.off);                // first position whose window passes T-1
+            if (hi >= rt0) L.edge[1] |= bit_range(T - 1 - hi, T - 1 - max(lo, rt0));
             if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
             else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
             else if (P.has_snr) {
@@ -564,7 +675,7 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             }
         }
         HSCMP_STAMP(5);                                         // segment maxima + bookkeeping
-        __syncthreads();                                        // B5: also drains this atom's residual / best stores
+        __syncthreads();                                        // B5: also drains this atom's residual / score stores
         HSCMP_STAMP(6);                                         // B5
         if (tid == kBook) {
             // deferred global stores of the bookkeeping: nobody waits for them (the duplicate scan
