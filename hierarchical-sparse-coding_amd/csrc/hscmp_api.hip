@@ -493,6 +493,10 @@ extern "C" int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, 
 }
 
 #ifdef HSCMP_DBG_STAMPS
+extern "C" int hscmp_debug_blocks(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hscmp::g_blk), (size_t)n * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 // diagnostic build only
 extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
 {

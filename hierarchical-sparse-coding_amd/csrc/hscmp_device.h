@@ -13,6 +13,12 @@
 
 namespace hscmp {
 
+#ifdef HSCMP_DBG_STAMPS
+// diagnostic build only (tools/read_stamps.py); never compiled into the product library
+__device__ unsigned long long g_stamps[16];      // per-phase cycle sums of workgroup 0
+__device__ unsigned long long g_blk[3 * 4096];   // per workgroup: start, end (100 MHz wall clock), XCC/HW id
+#endif
+
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxSeg = 1024;   // segment maxima kept in LDS per signal

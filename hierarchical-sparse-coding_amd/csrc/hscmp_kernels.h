@@ -296,6 +296,15 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
     const R* __restrict__ wts = S.weights;
+#ifdef HSCMP_DBG_STAMPS
+    if (tid == 0 && b < 4096) {
+        g_blk[3 * b + 0] = wall_clock64();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_blk[3 * b + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     Recorr::prologue(P, S, A, plds);
 
     // ---- prologue: segment maxima of the per-position best (and of |residual|)
@@ -554,6 +563,9 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     }
 
     __syncthreads();
+#ifdef HSCMP_DBG_STAMPS
+    if (tid == 0 && b < 4096) g_blk[3 * b + 1] = wall_clock64();
+#endif
     Recorr::epilogue(P, S, A, plds);
     if (tid == 0) {
         stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;

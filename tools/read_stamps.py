@@ -22,3 +22,26 @@ print('B=%d atoms=%d loop %.3f ms' % (B, n, eng.last_kernel_ms()[2]))
 for i, nm in enumerate(names):
     print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
 print('  %-18s %8.0f cycles/atom (sum; the select between atoms is not stamped)' % ('total', v[:8].sum() / n))
+
+# per-workgroup residency (diagnostic build)
+try:
+    nb = min(B, 4096)
+    blk = (ctypes.c_ulonglong * (3 * nb))()
+    lib.hscmp_debug_blocks(blk, nb)
+    a = np.array(list(blk), dtype=np.uint64).reshape(nb, 3)
+    st = a[:, 0].astype(np.float64); en = a[:, 1].astype(np.float64)
+    t0 = st.min(); st = (st - t0) / 100.0; en = (en - t0) / 100.0      # us (100 MHz)
+    dur = en - st
+    print('workgroups %d: duration us min %.0f median %.0f max %.0f; last end %.0f us' % (nb, dur.min(), np.median(dur), dur.max(), en.max()))
+    for tt in np.linspace(0, en.max(), 12)[:-1]:
+        print('  t=%7.0f us resident=%d' % (tt, int(np.sum((st <= tt) & (en > tt)))))
+    hw = a[:, 2]
+    xcc = (hw >> np.uint64(32)).astype(np.int64); hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
+    cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 0x7; sh_ = (hwid >> 12) & 1
+    key = xcc * 1000 + se * 100 + sh_ * 50 + cu
+    first = st < 50
+    import collections
+    cnt = collections.Counter(key[first].tolist())
+    print('first-round workgroups: %d on %d distinct CUs; per-CU histogram %s' % (int(first.sum()), len(cnt), dict(collections.Counter(cnt.values()))))
+except Exception as ex:
+    print('no block info', ex)
