@@ -57,7 +57,7 @@ def test_resumed_launches_equal_one_launch():
     from hsc_amd import _native
     x, D = _setup(T=1024, K=16, W=16, n=10)
     # atoms near both edges exercise the edge-row flags across launches
-    x = x.copy(); x[:20] += 1.5 * D[3][-20:]; x[-12:] -= 2.0 * D[5][:12]
+    x = x.copy(); x[:10] += 1.5 * D[3][-10:]; x[-12:] -= 2.0 * D[5][:12]
     eng = _native.Engine(0)
     eng.set_dictionary(D)
     eps = float(np.finfo(np.float32).eps)
