@@ -8,6 +8,7 @@
 
 #include "hscmp_kernels.h"
 #include "hscmp_mfma.h"
+#include "hscmp_sparse.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -29,11 +30,14 @@ struct hscmp_ctx {
     void* d_D = nullptr;
     void* d_w = nullptr;      // nullptr when no weights
     void* d_Dfrag = nullptr;  // MFMA fragment-ordered copy (f32, F == 1)
+    void* d_Dt = nullptr;     // [W][F][K] transposed copy for the sparsity-aware kernels (F > 1)
+    void* d_scratch = nullptr;
     size_t Dfrag_bytes = 0;
     // batch workspace
     int B = 0, T = 0, cap = 0, maxsel = 0;
     bool have_batch = false;
     size_t caps[16] = {0};
+    size_t cap_scratch = 0;
     void* d_x = nullptr;      // staging for host inputs
     void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
@@ -99,7 +103,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 
 static void free_all(hscmp_ctx* c)
 {
-    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
+    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_scratch, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
                     c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -144,6 +148,7 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     if (ctx->d_D) { (void)hipFree(ctx->d_D); ctx->d_D = nullptr; }
     if (ctx->d_w) { (void)hipFree(ctx->d_w); ctx->d_w = nullptr; }
     if (ctx->d_Dfrag) { (void)hipFree(ctx->d_Dfrag); ctx->d_Dfrag = nullptr; ctx->Dfrag_bytes = 0; }
+    if (ctx->d_Dt) { (void)hipFree(ctx->d_Dt); ctx->d_Dt = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_D, nD));
     HIP_TRY(ctx, hipMemcpy(ctx->d_D, D, nD, hipMemcpyHostToDevice));
     if (weights) {
@@ -152,6 +157,16 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     }
     ctx->K = K; ctx->W = W; ctx->F = F; ctx->dtype = dtype;
     ctx->have_batch = false;
+    if (F > 1) {
+        // Dt[w][f][k] = D[k][w][f]: atom index contiguous, for the sparsity-aware kernels
+        std::vector<char> dt(nD);
+        for (int k = 0; k < K; ++k)
+            for (int w = 0; w < W; ++w)
+                for (int f = 0; f < F; ++f)
+                    memcpy(&dt[(((size_t)w * F + f) * K + k) * es], (const char*)D + (((size_t)k * W + w) * F + f) * es, es);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Dt, nD));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Dt, dt.data(), nD, hipMemcpyHostToDevice));
+    }
     // MFMA operand image of the dictionary (f32 only): built once, reused by every encode
     if (dtype == HSCMP_F32 && mfma_supported(K, W, F)) {
         std::vector<float> frag;
@@ -219,6 +234,7 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
         {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
         {(void**)&ctx->d_edge, &ctx->caps[15], B * 2 * sizeof(unsigned long long)},
+        {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)(2 * P.W - 1) * P.K * es : 0},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -251,6 +267,42 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
     return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
+static bool use_sparse(const hscmp_ctx* ctx, int T)
+{
+    if (getenv("HSCMP_FORCE_GENERIC")) return false;
+    // multi-feature inputs (hierarchical levels >= 1); the row-flag bitmap must fit in LDS
+    return ctx->F > 1 && ctx->d_Dt != nullptr && T <= 262144 && ctx->W <= 32768;
+}
+
+template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx)
+{
+    SparseArgs<R> A;
+    A.Dt = (const R*)ctx->d_Dt; A.scratch = (R*)ctx->d_scratch;
+    return A;
+}
+
+template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const DevParams& P0)
+{
+    State<R> S = make_state<R>(ctx);
+    DevParams P = P0;
+    set_segments(P, SparseRecorr<R>::kMaxSegments);
+    const size_t lds = ((sizeof(typename SparseRecorr<R>::Shared) + 15) / 16) * 16 + sizeof(SparseLds<R>);
+    auto kern = iterate_kernel<R, SparseRecorr<R>>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx));
+    return HSCMP_OK;
+}
+
+template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const DevParams& P)
+{
+    State<R> S = make_state<R>(ctx);
+    const size_t lds = ((sizeof(SparseLds<R>) + 15) / 16) * 16 + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
+    auto kern = corr_init_sparse_kernel<R>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx));
+    return HSCMP_OK;
+}
+
 template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams& P0)
 {
     State<R> S = make_state<R>(ctx);
@@ -273,7 +325,9 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
         int rc = mfma_launch_corr_init(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mf = true;
     }
-    if (!mf) {
+    const bool sp = use_sparse(ctx, P.T);
+    if (sp) { int rc = launch_corr_init_sparse<R>(ctx, P); if (rc) return rc; }
+    if (!mf && !sp) {
         dim3 grid((P.T + kThreads - 1) / kThreads, P.B);
         hipLaunchKernelGGL((corr_init_generic_kernel<R, false>), grid, dim3(kThreads), 0, ctx->stream, P, S,
                            (const R*)ctx->d_resid, P.off, P.T, (R*)nullptr);
@@ -284,11 +338,13 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
         int rc = mfma_launch_iterate(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mfi = true;
     }
-    if (!mfi) launch_iterate<R>(ctx, P);
+    if (sp) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
+    else if (!mfi) launch_iterate<R>(ctx, P);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true;
-    ctx->variant = std::string(mf ? "mfma" : "generic") + "_init+" + (mfi ? "mfma" : "generic") + "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
+    ctx->variant = std::string(mf ? "mfma" : sp ? "sparse" : "generic") + "_init+" + (mfi ? "mfma" : sp ? "sparse" : "generic") +
+                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
     return HSCMP_OK;
 }
 
@@ -337,7 +393,10 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         State<float> S = make_state<float>(ctx);
         if (mfma_launch_iterate(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
     }
-    if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }
+    if (use_sparse(ctx, P.T)) {
+        int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);
+        if (rc) return rc;
+    } else if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return HSCMP_OK;

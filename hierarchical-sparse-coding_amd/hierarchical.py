@@ -124,6 +124,40 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         residual = self._calculateResidual(sequence, coefficients, multilevelDict)
         return coefficients, residual
 
+    def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
+                                 returnDistributed=True):
+        """Batch form (the reference has no batch axis): `sequences` [B,T] or [B,T,F]; every level encodes
+        all B signals in one GPU call.  Returns (list over signals of per-level coefficient lists,
+        residuals [B,T(,F)] float64, per-level kernel timings)."""
+        assert _is_multilevel_dict(multilevelDict)
+        if self.method != 'cmp':
+            self._level_coder(None)                       # raises for the methods this engine does not provide
+        B = sequences.shape[0]
+        inputs = np.asarray(sequences)
+        per_level, timings = [], []
+        for level in range(multilevelDict.getNbLevels()):
+            if toleranceSnr is not None and isinstance(toleranceSnr, collections.abc.Iterable):
+                targetSnr = toleranceSnr[level]
+            else:
+                targetSnr = toleranceSnr
+            D = multilevelDict.getRawDictionary(level)
+            nbSingletons = D.shape[0] - multilevelDict.countsNoSingletons[level]
+            weights = np.ones((D.shape[0],), dtype=D.dtype)
+            weights[:nbSingletons] = singletonWeight
+            cmp = ConvolutionalMatchingPursuit(device=self.device)
+            res = cmp.computeCoefficientsBatch(inputs, D, toleranceSnr=targetSnr, nbBlocks=nbBlocks, weights=weights)
+            per_level.append(res.coefficients)
+            timings.append(dict(level=level, variant=res.variant, kernel_ms=[float(v) for v in res.kernel_ms],
+                                selections=int(res.stats[:, 4].sum())))
+            if level + 1 < multilevelDict.getNbLevels():
+                inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
+        coefficients, residuals = [], []
+        for b in range(B):
+            cb = self._postprocessCoefficients([per_level[l][b] for l in range(len(per_level))], multilevelDict, returnDistributed)
+            coefficients.append(cb)
+            residuals.append(self._calculateResidual(sequences[b], cb, multilevelDict))
+        return coefficients, np.stack(residuals, axis=0), timings
+
     def computeCoefficientsFromLevel(self, sequence, coefficients, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None,
                                      toleranceSnr=None, nbBlocks=1, minCoefficients=None, singletonWeight=0.5, stopCondition=None,
                                      returnDistributed=True):

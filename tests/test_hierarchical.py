@@ -122,3 +122,21 @@ def test_hierarchical_gpu_vs_reference_golden(name):
     from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, HierarchicalConvolutionalSparseCoder
     hcsc = HierarchicalConvolutionalSparseCoder(_mld(), HierarchicalConvolutionalMatchingPursuit(method='cmp'))
     _check_case(hcsc, _golden(), name)
+
+
+@pytest.mark.gpu
+def test_hierarchical_batch_equals_per_signal():
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+    z = _golden()
+    mld = _mld().withSingletonBases()
+    rs = np.random.RandomState(9)
+    xs = np.stack([z['x'], (z['x'][::-1]).copy(), (z['x'] * 0.5 + 0.02 * rs.standard_normal(z['x'].shape)).astype(np.float32)])
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9)
+    coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
+    assert len(timings) == 3 and timings[1]['variant'].startswith('sparse')
+    for b in range(xs.shape[0]):
+        c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
+        for l in range(3):
+            assert (coefs[b][l] != c1[l]).nnz == 0
+        assert np.array_equal(residuals[b], r1)
