@@ -158,7 +158,7 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     ctx->K = K; ctx->W = W; ctx->F = F; ctx->dtype = dtype;
     ctx->have_batch = false;
     if (F > 1) {
-        // Dt[w][f][k] = D[k][w][f]: atom index contiguous, for the sparsity-aware kernels
+        // Dt[w][f][k] = D[k][w][f]: atom index contiguous, for the gathered-window kernels
         std::vector<char> dt(nD);
         for (int k = 0; k < K; ++k)
             for (int w = 0; w < W; ++w)
@@ -267,11 +267,19 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
     return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
-static bool use_sparse(const hscmp_ctx* ctx, int T)
+// Loop policy for multi-feature inputs (hierarchical levels >= 1): SparseRecorr gathers the non-zeros
+// of the window into LDS and reads the transposed dictionary coalesced.
+static bool use_sparse_loop(const hscmp_ctx* ctx)
 {
-    if (getenv("HSCMP_FORCE_GENERIC")) return false;
-    // multi-feature inputs (hierarchical levels >= 1); the row-flag bitmap must fit in LDS
-    return ctx->F > 1 && ctx->d_Dt != nullptr && T <= 262144 && ctx->W <= 32768;
+    if (getenv("HSCMP_FORCE_DENSE")) return false;
+    // multi-feature inputs only (measured: for dense single-feature windows the dense chain is 3x faster)
+    return ctx->F > 1 && ctx->d_Dt != nullptr && ctx->W <= 16384 && ctx->F <= 32767;   // (f << 16) | row key
+}
+// Sparse INITIAL correlation: only for multi-feature inputs (hierarchical levels >= 1, almost all
+// zero); a dense single-feature signal is cheaper through the dense generic kernel.
+static bool use_sparse_init(const hscmp_ctx* ctx, int T)
+{
+    return use_sparse_loop(ctx) && ctx->F > 1 && T <= 262144;
 }
 
 template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx)
@@ -308,7 +316,7 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
     State<R> S = make_state<R>(ctx);
     DevParams P = P0;
     set_segments(P, GenericRecorr<R>::kMaxSegments);
-    const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16;
+    const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
     hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S,
                        typename GenericRecorr<R>::Args{});
     return HSCMP_OK;
@@ -325,9 +333,9 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
         int rc = mfma_launch_corr_init(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mf = true;
     }
-    const bool sp = use_sparse(ctx, P.T);
-    if (sp) { int rc = launch_corr_init_sparse<R>(ctx, P); if (rc) return rc; }
-    if (!mf && !sp) {
+    const bool spi = !mf && use_sparse_init(ctx, P.T);
+    if (spi) { int rc = launch_corr_init_sparse<R>(ctx, P); if (rc) return rc; }
+    if (!mf && !spi) {
         dim3 grid((P.T + kThreads - 1) / kThreads, P.B);
         hipLaunchKernelGGL((corr_init_generic_kernel<R, false>), grid, dim3(kThreads), 0, ctx->stream, P, S,
                            (const R*)ctx->d_resid, P.off, P.T, (R*)nullptr);
@@ -338,12 +346,13 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
         int rc = mfma_launch_iterate(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
         if (rc == 0) mfi = true;
     }
-    if (sp) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
+    const bool spl = !mfi && use_sparse_loop(ctx);
+    if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
     else if (!mfi) launch_iterate<R>(ctx, P);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true;
-    ctx->variant = std::string(mf ? "mfma" : sp ? "sparse" : "generic") + "_init+" + (mfi ? "mfma" : sp ? "sparse" : "generic") +
+    ctx->variant = std::string(mf ? "mfma" : spi ? "sparse" : "generic") + "_init+" + (mfi ? "mfma" : spl ? "gathered" : "generic") +
                    "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
     return HSCMP_OK;
 }
@@ -393,7 +402,7 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         State<float> S = make_state<float>(ctx);
         if (mfma_launch_iterate(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
     }
-    if (use_sparse(ctx, P.T)) {
+    if (!mfi && use_sparse_loop(ctx)) {
         int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);
         if (rc) return rc;
     } else if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }

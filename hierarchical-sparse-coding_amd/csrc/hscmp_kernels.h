@@ -215,11 +215,12 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*) {}
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
-    static size_t extra_lds_bytes(const DevParams&) { return 0; }
+    static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
+    static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G,
-                                               SH& sh, const Args&, char*, int p)
+                                               SH& sh, const Args&, char* lds, int p)
     {
         const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x;
         const int nrows = 2 * W - 1;
@@ -229,6 +230,18 @@ template <typename R> struct GenericRecorr {
         const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
         const int nslice = eidx - sidx + 1;
         const bool interior = (tstart >= 0) && (tend <= T - 1);
+        // reflect-padded residual span (np.pad 'reflect', :1046) staged in LDS when it fits
+        R* win = reinterpret_cast<R*>(lds);
+        const int span = 3 * W - 2;
+        const bool staged = (size_t)span * F * sizeof(R) <= (size_t)kWinBytes;
+        if (staged) {
+            for (int i = tid; i < span * F; i += kThreads) {
+                const int jj = i / F, ff = i - jj * F;
+                const int gi = interior ? tstart + jj : reflect_index(tstart + jj, sidx, nslice);
+                win[i] = G.r[(int64_t)gi * F + ff];
+            }
+            __syncthreads();
+        }
         const int rpp = nrows < kThreads ? nrows : kThreads;
         int ngrp = kThreads / rpp;
         if (ngrp > K) ngrp = K;
@@ -246,12 +259,20 @@ template <typename R> struct GenericRecorr {
                 for (int k = k0; k < k1; ++k) {
                     const R* dk = D + (int64_t)k * W * F;
                     R acc = (R)0;
-                    for (int f = 0; f < F; ++f)
-                        for (int w = 0; w < W; ++w) {
-                            int gi = t - P.off + w;
-                            if (!interior) gi = reflect_index(gi, sidx, nslice);   // np.pad 'reflect', :1046
-                            acc = rfma(G.r[(int64_t)gi * F + f], dk[w * F + f], acc);
+                    if (staged) {
+                        const R* wj = win + (int64_t)j * F;          // row j's window starts at span row j
+                        for (int f = 0; f < F; ++f) {
+#pragma unroll 8
+                            for (int w = 0; w < W; ++w) acc = rfma(wj[w * F + f], dk[w * F + f], acc);
                         }
+                    } else {
+                        for (int f = 0; f < F; ++f)
+                            for (int w = 0; w < W; ++w) {
+                                int gi = t - P.off + w;
+                                if (!interior) gi = reflect_index(gi, sidx, nslice);   // np.pad 'reflect', :1046
+                                acc = rfma(G.r[(int64_t)gi * F + f], dk[w * F + f], acc);
+                            }
+                    }
                     const R sc = score_of(acc, k, S.weights);
                     if (sc > bs) { bs = sc; bc = acc; bk = k; }
                 }

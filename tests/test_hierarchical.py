@@ -134,7 +134,7 @@ def test_hierarchical_batch_equals_per_signal():
     hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
     kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9)
     coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
-    assert len(timings) == 3 and timings[1]['variant'].startswith('sparse')
+    assert len(timings) == 3 and timings[1]['variant'].startswith('sparse_init+gathered_loop')
     for b in range(xs.shape[0]):
         c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
         for l in range(3):
