@@ -21,7 +21,8 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
-           'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_encode_batch',
+           'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
+           'hscmp_update_inner_products', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_continue', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
@@ -74,6 +75,9 @@ def load_library():
     lib.hscmp_synchronize.argtypes = [vp]
     lib.hscmp_set_dictionary.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.hscmp_convolve1d.argtypes = [vp, vp, ci, ci, vp]
+    lib.hscmp_select_best_atoms.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, vp, vp, vp, vp, ci,
+                                            ctypes.POINTER(ctypes.c_int32)]
+    lib.hscmp_update_inner_products.argtypes = [vp, vp, vp, ci, ci]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_continue.argtypes = [vp, ci]
@@ -190,6 +194,33 @@ class Engine(object):
         out = np.empty((Tout, self.K), dtype=self.dtype)
         self._check(self._lib.hscmp_convolve1d(self._h, _ptr(x2), T, 1 if same else 0, _ptr(out)), 'hscmp_convolve1d')
         return out
+
+    def select_best_atoms(self, innerProducts, filterWidth, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
+        """modeling.py:899-982 on a materialised table [T,K]; returns (t, k, c) in the reference's order."""
+        ip = np.ascontiguousarray(innerProducts)
+        code = dtype_code(ip.dtype)
+        T, K = ip.shape
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=ip.dtype)
+        cap = T + 2
+        t = np.empty(cap, dtype=np.int32)
+        k = np.empty(cap, dtype=np.int32)
+        c = np.empty(cap, dtype=ip.dtype)
+        n = ctypes.c_int32(0)
+        thres = float('nan') if nullCoeffThres is None else float(nullCoeffThres)
+        self._check(self._lib.hscmp_select_best_atoms(self._h, _ptr(ip), T, K, int(filterWidth), code, nb_blocks_code(nbBlocks),
+                                                      int(bool(offset)), ctypes.c_double(thres), _ptr(w), _ptr(t), _ptr(k), _ptr(c),
+                                                      cap, ctypes.byref(n)), 'hscmp_select_best_atoms')
+        self._batch = None
+        return t[:n.value].copy(), k[:n.value].copy(), c[:n.value].copy()
+
+    def update_inner_products(self, innerProducts, residual, position):
+        """modeling.py:1018-1051 for one atom centre, in place on innerProducts [T,K] (dictionary of the context)."""
+        assert innerProducts.flags.c_contiguous and innerProducts.dtype == self.dtype
+        r = np.ascontiguousarray(residual.reshape((residual.shape[0], -1)), dtype=self.dtype)
+        assert r.shape[1] == self.F and innerProducts.shape == (r.shape[0], self.K)
+        self._check(self._lib.hscmp_update_inner_products(self._h, _ptr(innerProducts), _ptr(r), r.shape[0], int(position)),
+                    'hscmp_update_inner_products')
+        return innerProducts
 
     def encode_batch(self, x, params):
         """x [B,T,F] host array of the dictionary dtype."""

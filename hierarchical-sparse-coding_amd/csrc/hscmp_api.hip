@@ -573,3 +573,116 @@ extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
     return 0;
 }
 #endif
+
+// ---- row-level entry points (modeling.py:899-982 and :1018-1051) -------------------------------------
+template <typename R>
+static int run_select(hscmp_ctx* ctx, const void* ip, int T, int K, int W, int nb_blocks, int offset, double thres,
+                      const void* weights, int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out)
+{
+    hscmp_params hp{};
+    hp.nb_nonzero_coefs = -1; hp.nb_blocks = nb_blocks; hp.tolerance_snr = NAN; hp.tolerance_residual_scale = NAN;
+    hp.null_coeff_thres = thres; hp.eps = 0.0; hp.max_events = 1; hp.max_rounds = 1;
+    // a throw-away geometry: only T, K, W matter for the selection
+    const int sK = ctx->K, sW = ctx->W, sF = ctx->F, sD = ctx->dtype;
+    ctx->K = K; ctx->W = W; ctx->F = 1; ctx->dtype = sizeof(R) == 8 ? HSCMP_F64 : HSCMP_F32;
+    DevParams P;
+    int rc = make_params(ctx, 1, T, &hp, &P);
+    if (rc == HSCMP_OK) rc = ensure_workspace(ctx, P, false);
+    R* d_ip = nullptr; R* d_w = nullptr;
+    hipError_t e = hipSuccess;
+    if (rc == HSCMP_OK) {
+        do {
+            if ((e = hipMalloc((void**)&d_ip, (size_t)T * K * sizeof(R))) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(d_ip, ip, (size_t)T * K * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if (weights) {
+                if ((e = hipMalloc((void**)&d_w, (size_t)K * sizeof(R))) != hipSuccess) break;
+                if ((e = hipMemcpyAsync(d_w, weights, (size_t)K * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            }
+            State<R> S = make_state<R>(ctx);
+            S.D = nullptr; S.weights = d_w;
+            hipLaunchKernelGGL((table_to_best_kernel<R>), dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
+                               (const R*)d_ip, T, K, (const R*)d_w, S.best_c, S.best_k);
+            int st[ST_COUNT] = {0};
+            st[ST_OFFSET] = offset ? 1 : 0;
+            if ((e = hipMemcpyAsync(ctx->d_stats, st, sizeof(st), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            P.select_only = 1; P.has_snr = 0; P.has_scale = 0;
+            set_segments(P, GenericRecorr<R>::kMaxSegments);
+            const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
+            hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(1), dim3(kThreads), lds, ctx->stream, P, S,
+                               typename GenericRecorr<R>::Args{});
+            if ((e = hipGetLastError()) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) break;
+            const int n = st[ST_EVENTS];
+            *n_out = n;
+            if (n > max_out) { rc = fail(ctx, HSCMP_ERR_INVALID, "hscmp_select_best_atoms: %d atoms selected, room for %d", n, max_out); break; }
+            if (n > 0) {
+                // the ordered list lives in the second half of the selection scratch
+                if ((e = hipMemcpy(out_t, ctx->d_sel_t + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+                if ((e = hipMemcpy(out_k, ctx->d_sel_k + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+                if ((e = hipMemcpy(out_c, (R*)ctx->d_sel_c + P.maxsel, (size_t)n * sizeof(R), hipMemcpyDeviceToHost)) != hipSuccess) break;
+            }
+        } while (0);
+        if (e != hipSuccess && rc == HSCMP_OK) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_select_best_atoms: %s", hipGetErrorString(e));
+    }
+    if (d_ip) (void)hipFree(d_ip);
+    if (d_w) (void)hipFree(d_w);
+    ctx->K = sK; ctx->W = sW; ctx->F = sF; ctx->dtype = sD;
+    ctx->have_batch = false;
+    return rc;
+}
+
+extern "C" int hscmp_select_best_atoms(hscmp_ctx* ctx, const void* ip, int T, int K, int W, hscmp_dtype dtype, int nb_blocks,
+                                       int offset, double null_coeff_thres, const void* weights,
+                                       int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_select_best_atoms: ctx is NULL");
+    if (!ip || !out_t || !out_k || !out_c || !n_out || T <= 0 || K <= 0 || W <= 0)
+        return fail(ctx, HSCMP_ERR_INVALID, "hscmp_select_best_atoms: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return dtype == HSCMP_F32
+        ? run_select<float>(ctx, ip, T, K, W, nb_blocks, offset, null_coeff_thres, weights, out_t, out_k, out_c, max_out, n_out)
+        : run_select<double>(ctx, ip, T, K, W, nb_blocks, offset, null_coeff_thres, weights, out_t, out_k, out_c, max_out, n_out);
+}
+
+template <typename R> static int run_update_rows(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p)
+{
+    const int K = ctx->K, W = ctx->W, F = ctx->F, nrows = 2 * W - 1;
+    R* d_r = nullptr; R* d_out = nullptr;
+    hipError_t e;
+    int rc = HSCMP_OK;
+    std::vector<R> rows((size_t)nrows * K);
+    do {
+        if ((e = hipMalloc((void**)&d_r, (size_t)T * F * sizeof(R))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&d_out, (size_t)nrows * K * sizeof(R))) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_r, residual, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        DevParams P{};
+        P.B = 1; P.T = T; P.K = K; P.W = W; P.F = F; P.off = (W - 1) / 2;
+        const int grid = (nrows * K + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL((update_rows_kernel<R>), dim3(grid), dim3(kThreads), 0, ctx->stream, P, (const R*)d_r, (const R*)ctx->d_D, p, d_out);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(rows.data(), d_out, rows.size() * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_update_inner_products: %s", hipGetErrorString(e));
+    if (rc == HSCMP_OK) {
+        R* tab = (R*)ip;
+        for (int row = 0; row < nrows; ++row) {               // overlapReplace clipping (utils.py:133-161)
+            const int t = p - (W - 1) + row;
+            if (t >= 0 && t < T) memcpy(tab + (size_t)t * K, rows.data() + (size_t)row * K, (size_t)K * sizeof(R));
+        }
+    }
+    if (d_r) (void)hipFree(d_r);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_update_inner_products: ctx is NULL");
+    if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_update_inner_products: no dictionary set");
+    if (!ip || !residual || T <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_update_inner_products: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ctx->dtype == HSCMP_F32 ? run_update_rows<float>(ctx, ip, residual, T, p) : run_update_rows<double>(ctx, ip, residual, T, p);
+}

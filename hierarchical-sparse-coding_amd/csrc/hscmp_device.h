@@ -42,6 +42,7 @@ struct DevParams {
     double eps;
     int cap;            // max events per signal
     int max_rounds;     // <= 0: until converged
+    int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
 };
 
 // segment size: the smallest power of two >= 64 that keeps the segment count within maxseg

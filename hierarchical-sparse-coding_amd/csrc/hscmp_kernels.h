@@ -88,6 +88,48 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
     }
 }
 
+// per-position best of a materialised inner-product table ip[T][K] (entry point of _selectBestAtoms)
+template <typename R>
+__global__ __launch_bounds__(kThreads) void table_to_best_kernel(const R* __restrict__ ip, int T, int K, const R* __restrict__ w,
+                                                                 R* __restrict__ bc, int* __restrict__ bk)
+{
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= T) return;
+    R bs = (R)-1, c = (R)0;
+    int kk = 0;
+    for (int k = 0; k < K; ++k) {
+        const R v = ip[(int64_t)t * K + k];
+        const R sc = score_of(v, k, w);
+        if (sc > bs) { bs = sc; c = v; kk = k; }
+    }
+    bc[t] = c;
+    bk[t] = kk;
+}
+
+// rows p-(W-1) .. p+(W-1) of the inner-product table from the reflect-padded residual span
+// (modeling.py:1018-1051, entry point of _updateInnerProducts): out[(2W-1)][K]
+template <typename R>
+__global__ __launch_bounds__(kThreads) void update_rows_kernel(DevParams P, const R* __restrict__ r, const R* __restrict__ D, int p,
+                                                               R* __restrict__ out)
+{
+    const int T = P.T, K = P.K, W = P.W, F = P.F;
+    const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);
+    const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend, nslice = eidx - sidx + 1;
+    const int nrows = 2 * W - 1;
+    for (int o = blockIdx.x * kThreads + threadIdx.x; o < nrows * K; o += gridDim.x * kThreads) {
+        const int row = o / K, k = o - row * K;
+        const int t = p - (W - 1) + row;
+        const R* dk = D + (int64_t)k * W * F;
+        R acc = (R)0;
+        for (int f = 0; f < F; ++f)
+            for (int w = 0; w < W; ++w) {
+                const int g = reflect_index(t - P.off + w, sidx, nslice);
+                acc = rfma(r[(int64_t)g * F + f], dk[w * F + f], acc);
+            }
+        out[o] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared state of the greedy loop
 // ------------------------------------------------------------------------------------------------
@@ -461,6 +503,14 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             nsel = sh.nsel;
         }
 
+        if (P.select_only) {
+            // _selectBestAtoms entry point (hscmp_select_best_atoms): the ordered list goes back as is
+            if (tid == 0) {
+                if (!P.blocked && nsel > 0) { ord_t[0] = p_sel; ord_k[0] = k_sel; ord_c[0] = c_sel; }
+                stats[ST_EVENTS] = nsel;
+            }
+            return;
+        }
         // =========================== apply the selected atoms (:1101-1142) ===========================
         bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
         for (int ai = 0; ai < nsel; ++ai) {

@@ -47,6 +47,42 @@ def addSingletonBases(dictionaries):
     return out
 
 
+EVENT_DTYPE = np.dtype('int32,int32,int32,float32')      # (time, level, atom index, coefficient)
+
+
+def convertSparseMatricesToEvents(coefficients):
+    """Per-level coefficient matrices -> the reference's event record array, sorted by time with the
+    reference's tie order (stable w.r.t. level, then COO order) (hsc/dataset.py:798-811)."""
+    times, levels, indices, values = [], [], [], []
+    for level, c in enumerate(coefficients):
+        c = c.tocoo()
+        times.append(np.asarray(c.row, dtype=np.int64))
+        levels.append(np.full(c.row.shape, level, dtype=np.int64))
+        indices.append(np.asarray(c.col, dtype=np.int64))
+        values.append(np.asarray(c.data))
+    if not times:
+        return np.zeros((0,), dtype=EVENT_DTYPE)
+    t = np.concatenate(times); l = np.concatenate(levels); i = np.concatenate(indices); v = np.concatenate(values)
+    order = np.argsort(t, kind='stable')                  # Python's sorted() is stable
+    events = np.zeros((len(t),), dtype=EVENT_DTYPE)
+    events['f0'] = t[order]; events['f1'] = l[order]; events['f2'] = i[order]; events['f3'] = v[order]
+    return events
+
+
+def convertEventsToSparseMatrices(events, counts, sequenceLength):
+    """Event records -> one CSR matrix [sequenceLength, count] per level (hsc/dataset.py:813-824)."""
+    import scipy.sparse
+    t = np.asarray(events['f0'], dtype=np.int64)
+    l = np.asarray(events['f1'], dtype=np.int64)
+    i = np.asarray(events['f2'], dtype=np.int64)
+    v = np.asarray(events['f3'])
+    out = []
+    for level, count in enumerate(counts):
+        m = l == level
+        out.append(scipy.sparse.coo_matrix((v[m], (t[m], i[m])), shape=(sequenceLength, count)).tocsr())
+    return out
+
+
 class MultilevelDictionary(object):
     """hsc/dataset.py:110-410 (container part)."""
 

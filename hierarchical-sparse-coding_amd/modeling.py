@@ -19,7 +19,7 @@ import numpy as np
 import scipy.sparse
 
 from . import _native
-from .utils import overlapAdd
+from .utils import overlapAdd, centered_span
 
 logger = logging.getLogger(__name__)
 
@@ -145,6 +145,51 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         self.device = device
         self.fig = None
         self.lastResult = None
+
+    # ---- the reference's overridable helpers, GPU backed (LoCOMP-style subclasses build on them) ----
+    def _selectBestAtoms(self, innerProducts, filterWidth, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
+        """hsc/modeling.py:899-982 on a materialised table [T,K]; returns the reference's list of Atom."""
+        if weights is not None:
+            assert len(weights) == innerProducts.shape[1]
+        dt = _compute_dtype(innerProducts.dtype)
+        eng = _native.default_engine(self.device)
+        t, k, c = eng.select_best_atoms(np.asarray(innerProducts, dtype=dt), filterWidth, nbBlocks, offset, nullCoeffThres,
+                                        None if weights is None else np.asarray(weights, dtype=dt))
+        return [Atom(int(p), int(f), cc, filterWidth) for p, f, cc in zip(t, k, c)]
+
+    def _updateCoefficients(self, coefficients, atoms, replace=True):
+        """hsc/modeling.py:984-994 (host: a handful of scalar updates of the sparse matrix)"""
+        for atom in atoms:
+            if replace:
+                coefficients[atom.position, atom.index] = atom.coefficient
+            else:
+                coefficients[atom.position, atom.index] += atom.coefficient
+        return coefficients
+
+    def _updateResidual(self, residual, energyResidual, atoms, D, eps=1e-16):
+        """hsc/modeling.py:996-1016 (host: W samples per atom)"""
+        energyLoss = 0.0
+        for atom in atoms:
+            s, e, es, ee = centered_span(residual.shape[0], atom.length, atom.position)
+            before = np.sum(np.square(residual[s:e]))
+            residual[s:e] += (-atom.coefficient * D[atom.index])[es:ee]
+            after = np.sum(np.square(residual[s:e]))
+            energyLoss += (before - after)
+        if energyLoss < 0.0 and np.abs(energyLoss) > eps:
+            logger.warning('Residual energy (%f) increased by %4.18f' % (energyResidual, -energyLoss))
+        energyResidual -= energyLoss
+        return residual, energyResidual
+
+    def _updateInnerProducts(self, innerProducts, residual, atoms, D):
+        """hsc/modeling.py:1018-1051: rows p-(W-1)..p+(W-1) re-correlated on the GPU, in place."""
+        dt = _compute_dtype(innerProducts.dtype, D.dtype)
+        if innerProducts.dtype != dt or not innerProducts.flags.c_contiguous:
+            raise TypeError('innerProducts must be a C-contiguous %s array' % dt)
+        eng = _native.default_engine(self.device)
+        eng.set_dictionary(np.asarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt))
+        for atom in atoms:
+            eng.update_inner_products(innerProducts, np.asarray(residual, dtype=dt), atom.position)
+        return innerProducts
 
     # ---------------------------------------------------------------------------------------
     def computeCoefficientsBatch(self, sequences, D, nbNonzeroCoefs=None, toleranceResidualScale=None,

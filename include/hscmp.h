@@ -102,6 +102,20 @@ int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W, int F, hsc
  * dictionary of the context. */
 int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, void* out);
 
+/* ConvolutionalMatchingPursuit._selectBestAtoms (modeling.py:899-982) on a materialised table
+ * ip [T][K] (host, dtype): single arg-max (nb_blocks = 1) or blocked selection (nb_blocks > 1,
+ * -1 = 'auto'; `offset` = half-block shift) with the null / interference filters and the |c| ordering.
+ * weights [K] or NULL; null_coeff_thres NaN = None.  Writes up to max_out atoms (position, atom
+ * index, coefficient in dtype) in the reference's output order, *n_out = count. */
+int hscmp_select_best_atoms(hscmp_ctx* ctx, const void* ip, int T, int K, int W, hscmp_dtype dtype, int nb_blocks,
+                            int offset, double null_coeff_thres, const void* weights,
+                            int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out);
+
+/* ConvolutionalMatchingPursuit._updateInnerProducts (modeling.py:1018-1051) for ONE atom centre p:
+ * re-correlates rows p-(W-1) .. p+(W-1) against the reflect-padded residual [T][F] (host) with the
+ * context's dictionary and replaces them in ip [T][K] (host, in place). */
+int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p);
+
 /* ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053-1169) for a batch of B
  * independent signals x [B][T][F] (host memory): initial correlation, then the greedy
  * select / subtract / local re-correlate loop, entirely on the GPU.  Results stay in the

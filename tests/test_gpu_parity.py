@@ -126,3 +126,55 @@ def test_config2_full_size_vs_reference_golden(kind, idx):
     assert gu.rel_err(data, z[name + '__csc_data']) <= 1e-5
     e = float(np.sum(np.square(residual.astype(np.float64))))
     assert abs(e - float(z[name + '__residual_energy'])) <= 1e-5 * float(z[name + '__residual_energy'])
+
+
+@pytest.mark.parametrize('name', [str(n) for n in gu.load('functions.npz')['names']])
+def test_select_best_atoms_entry_point_vs_reference(name):
+    """Row a2 on its own: _selectBestAtoms (modeling.py:899-982) through hscmp_select_best_atoms on the
+    reference's table, 9 modes per case (single / blocked / 'auto', offsets, weights): exact."""
+    z = gu.load('functions.npz')
+    ip = z[name + '__same']
+    W = z[name + '__D'].shape[1]
+    cmp = _cmp()
+    for i in range(int(z[name + '__nsel'])):
+        nb = int(z['%s__sel%d_nb' % (name, i)])
+        off = bool(int(z['%s__sel%d_offset' % (name, i)]))
+        wkey = '%s__sel%d_weights' % (name, i)
+        w = z[wkey] if wkey in z else None
+        atoms = cmp._selectBestAtoms(ip, W, nbBlocks='auto' if nb == -1 else nb, offset=off, nullCoeffThres=1e-16, weights=w)
+        assert [a.position for a in atoms] == z['%s__sel%d_t' % (name, i)].tolist()
+        assert [a.index for a in atoms] == z['%s__sel%d_k' % (name, i)].tolist()
+        assert np.array_equal(np.array([a.coefficient for a in atoms], dtype=ip.dtype), z['%s__sel%d_c' % (name, i)])
+        assert all(a.length == W for a in atoms)
+
+
+def test_select_best_atoms_reference_kat():
+    """tests/hsc/test_modeling.py:272-325 through the GPU entry point."""
+    cmp = _cmp()
+    ip = np.arange(256).reshape((64, 4)).astype(np.float64)
+    ip[-1] = ip[-1][::-1]
+    pos = lambda atoms: ([a.position for a in atoms], [a.index for a in atoms])
+    assert pos(cmp._selectBestAtoms(ip, 5, 4, offset=False)) == ([63, 47, 31, 15], [0, 3, 3, 3])
+    assert pos(cmp._selectBestAtoms(ip, 5, 4, offset=True)) == ([63, 55, 39, 23, 7], [0, 3, 3, 3, 3])
+    assert pos(cmp._selectBestAtoms(ip, 3, 'auto', offset=False)) == ([63, 59, 47, 35, 23, 11], [0, 3, 3, 3, 3, 3])
+    assert pos(cmp._selectBestAtoms(ip, 5, 5, offset=False)) == ([59, 47, 35, 23, 11], [3, 3, 3, 3, 3])
+
+
+@pytest.mark.parametrize('name', [str(n) for n in gu.load('functions.npz')['names']])
+def test_update_inner_products_entry_point_vs_reference(name):
+    """Row a5 on its own: _updateInnerProducts (modeling.py:1018-1051) incl. the reflect-padding quirk at
+    both edges, through hscmp_update_inner_products: bit-exact vs the oracle, 1e-5 vs the reference."""
+    from hsc_amd.modeling import Atom
+    orc = _oracle()
+    z = gu.load('functions.npz')
+    D = z[name + '__D']
+    ip = z[name + '__same'].copy()
+    ipo = ip.copy()
+    cmp = _cmp()
+    for j in range(int(z[name + '__nupd'])):
+        p = int(z['%s__upd%d_p' % (name, j)])
+        r = z['%s__upd%d_r' % (name, j)]
+        cmp._updateInnerProducts(ip, r, [Atom(p, 0, 1.0, D.shape[1])], D)
+        orc.update_inner_products(ipo, r, D, p)
+        assert np.array_equal(ip, ipo)
+        assert float(np.max(np.abs(ip.astype(np.float64) - z['%s__upd%d_ip' % (name, j)]))) <= 20 * TOL[ip.dtype]

@@ -140,3 +140,21 @@ def test_hierarchical_batch_equals_per_signal():
         for l in range(3):
             assert (coefs[b][l] != c1[l]).nnz == 0
         assert np.array_equal(residuals[b], r1)
+
+
+def test_events_wire_format_matches_reference():
+    """hsc/dataset.py:798-824: coefficient matrices <-> (time, level, index, coefficient) records."""
+    from hsc_amd.dataset import convertSparseMatricesToEvents, convertEventsToSparseMatrices
+    z = _golden()
+    counts = [z['single_raw%d' % l].shape[0] for l in range(3)]
+    coefs = [scipy.sparse.csc_matrix((z['case_a__level%d_data' % l], (z['case_a__level%d_row' % l], z['case_a__level%d_col' % l])),
+                                     shape=(512, counts[l])) for l in range(3)]
+    ev = convertSparseMatricesToEvents(coefs)
+    assert ev.dtype == np.dtype('int32,int32,int32,float32')
+    assert np.array_equal(ev['f0'], z['case_a__events_t']) and np.array_equal(ev['f1'], z['case_a__events_l'])
+    assert np.array_equal(ev['f2'], z['case_a__events_i']) and np.array_equal(ev['f3'], z['case_a__events_c'])
+    back = convertEventsToSparseMatrices(ev, counts, 512)
+    for l, b in enumerate(back):
+        row, col, data = gu.csc_triplets(b)
+        assert np.array_equal(row, z['case_a__back%d_row' % l]) and np.array_equal(col, z['case_a__back%d_col' % l])
+        assert np.array_equal(data, z['case_a__back%d_data' % l])
