@@ -24,8 +24,9 @@ def _is_multilevel_dict(obj):
 
 
 class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
-    """hsc/modeling.py:1427-1654.  `method`: 'cmp' runs on the GPU engine; the reference's other
-    methods ('locomp' -- its default --, 'mptk-mp', 'mptk-cmp') are not part of this engine."""
+    """hsc/modeling.py:1427-1654.  `method`: 'cmp' (persistent-kernel greedy engine) or 'locomp' (the
+    reference's default: host loop over the GPU entry points, hsc_amd.locomp); the MPTK bindings
+    ('mptk-mp', 'mptk-cmp') are not provided."""
 
     def __init__(self, method='locomp', device=0):
         self.method = method
@@ -34,9 +35,12 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
     def _level_coder(self, D):
         if self.method == 'cmp':
             return ConvolutionalSparseCoder(D, ConvolutionalMatchingPursuit(device=self.device))
-        if self.method in ('locomp', 'mptk-mp', 'mptk-cmp'):
-            raise NotImplementedError("method='%s' is not provided by the MI355X engine (greedy 'cmp' only); "
-                                      "construct HierarchicalConvolutionalMatchingPursuit(method='cmp')" % self.method)
+        if self.method == 'locomp':
+            from .locomp import LoCOMP
+            return ConvolutionalSparseCoder(D, LoCOMP(device=self.device))
+        if self.method in ('mptk-mp', 'mptk-cmp'):
+            raise NotImplementedError("method='%s' needs the external MPTK toolkit, which this engine does not bind; "
+                                      "use method='cmp' or 'locomp'" % self.method)
         raise Exception('Unsupported sparse coding method: %s' % (self.method))
 
     def _encode_levels(self, input, coefficients, fromLevel, multilevelDict, toleranceSnr, nbBlocks, singletonWeight):
@@ -131,7 +135,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         residuals [B,T(,F)] float64, per-level kernel timings)."""
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
-            self._level_coder(None)                       # raises for the methods this engine does not provide
+            raise NotImplementedError("computeCoefficientsBatch runs the greedy engine only: method='cmp'")
         B = sequences.shape[0]
         inputs = np.asarray(sequences)
         per_level, timings = [], []

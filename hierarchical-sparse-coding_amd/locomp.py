@@ -1,0 +1,136 @@
+"""LoCOMP -- low-complexity orthogonal matching pursuit (reference: hsc/modeling.py:1191-1425;
+Mailhe et al., "A low complexity Orthogonal Matching Pursuit for sparse signal approximation with
+shift-invariant dictionaries", ICASSP 2009).
+
+Same outer loop as the greedy coder, but after each selection the coefficients of all previously
+selected atoms whose support overlaps the new one are re-fitted jointly (least squares on the local
+residual), then the residual and the inner products are updated for every atom of that group.
+
+The heavy operations run on the GPU through the same C ABI as the greedy coder -- initial correlation
+(hscmp_convolve1d), selection (hscmp_select_best_atoms), local re-correlation
+(hscmp_update_inner_products); the loop itself and the tiny least-squares systems (a handful of atoms
+by ~3W samples, np.linalg.pinv as in the reference, :1326) are host side.  The materialised table
+travels with every selection call, so this coder targets the reference's use of LoCOMP (moderate T);
+the table-free persistent-kernel engine is ConvolutionalMatchingPursuit.
+"""
+import logging
+
+import numpy as np
+import scipy.sparse
+
+from .modeling import Atom, ConvolutionalMatchingPursuit, _compute_dtype, convolve1d
+from .utils import overlapAdd, peek
+
+logger = logging.getLogger(__name__)
+
+
+class LoCOMP(ConvolutionalMatchingPursuit):
+
+    def __init__(self, verbose=False, device=0):
+        super(LoCOMP, self).__init__(verbose, device)
+
+    def _findCommonSupportAtoms(self, atom, coefficients, D):
+        """Previously selected atoms in the neighbourhood of `atom` (:1222-1241).  As in the reference
+        the exclusion test compares the window-relative row with the absolute position, and drops
+        every entry that shares the atom's index."""
+        T, W = coefficients.shape[0], D.shape[1]
+        start, end = atom.getPositionSpanIndices(T)
+        start = max(start - W // 2, 0)
+        end = min(end + (W // 2 - 1 if W % 2 == 0 else W // 2), T)
+        sub = coefficients[start:end + 1, :].tocoo()
+        return [Atom(start + int(r), int(k), c, W) for r, k, c in zip(sub.row, sub.col, sub.data)
+                if r != atom.position and k != atom.index]
+
+    def _getDictionaryFromSupportAtoms(self, sequence, atoms, D):
+        """Local dictionary of the group: every atom placed on the union of the supports (:1243-1265)."""
+        lo = min(a.getPositionSpanIndices(sequence.shape[0])[0] for a in atoms)
+        hi = max(a.getPositionSpanIndices(sequence.shape[0])[1] for a in atoms)
+        Dsup = []
+        for a in atoms:
+            s = np.zeros((hi - lo + 1,) + sequence.shape[1:], dtype=D.dtype)
+            overlapAdd(s, D[a.index], a.position - lo, copy=False)
+            Dsup.append(s)
+        return np.stack(Dsup), sequence[lo:hi + 1]
+
+    def computeCoefficients(self, sequence, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
+                            nbBlocks=1, minCoefficients=1e-16, weights=None, stopCondition=None):
+        """hsc/modeling.py:1267-1425"""
+        assert sequence.ndim == 1 or sequence.ndim == 2
+        assert D.ndim == 2 or D.ndim == 3
+        eps = np.finfo(D.dtype).eps
+        squeezeOutput = sequence.ndim == 1 or D.ndim == 2
+        if sequence.ndim == 1:
+            sequence = sequence[:, np.newaxis]
+        if D.ndim == 2:
+            D = D[:, :, np.newaxis]
+        dt = _compute_dtype(sequence.dtype, D.dtype)
+
+        energySignal = np.sum(np.square(sequence))
+        residual = np.copy(sequence)
+        energyResidual = energySignal
+        coefficients = scipy.sparse.lil_matrix((sequence.shape[0], D.shape[0]))
+        innerProducts = np.ascontiguousarray(convolve1d(residual, D, padding='same', device=self.device), dtype=dt)   # :1293
+
+        offset = False
+        converged = False
+        while not converged:
+            atoms = self._selectBestAtoms(innerProducts, nbBlocks=nbBlocks, filterWidth=D.shape[1], offset=offset,
+                                          nullCoeffThres=minCoefficients, weights=weights)
+            if toleranceSnr is not None and len(atoms) > 1:                       # weak-atom filter :1303-1312
+                limit = energySignal / (10.0 ** (toleranceSnr / 10.0)) / np.prod(sequence.shape)
+                atoms = [a for a in atoms if np.mean(np.square(peek(residual, a.length, a.position))) >= limit]
+
+            for atom in atoms:
+                if coefficients[atom.position, atom.index] != 0.0:
+                    logger.warning('Redundant atom selected: %s' % (str(atom)))
+                lastEnergyResidual = energyResidual
+                group = self._findCommonSupportAtoms(atom, coefficients, D)
+                if len(group) > 0:
+                    # joint least-squares re-fit of the group on the local residual (:1322-1341)
+                    group = [atom] + group
+                    Dsup, residualSup = self._getDictionaryFromSupportAtoms(residual, group, D)
+                    DsupF = Dsup.reshape((Dsup.shape[0], -1))
+                    fitted = np.dot(np.linalg.pinv(DsupF).T, residualSup.flatten()).flatten()
+                    for a, c in zip(group, fitted):
+                        a.coefficient = c
+                else:
+                    group = [atom]
+                coefficients = self._updateCoefficients(coefficients, group, replace=False)
+                residual, energyResidual = self._updateResidual(residual, energyResidual, group, D, eps)
+                innerProducts = self._updateInnerProducts(innerProducts, residual, group, D)
+
+                if energyResidual < eps:                                          # :1360-1365
+                    converged = True
+                    break
+                snr = 10.0 * np.log10(energySignal / energyResidual)
+                if nbNonzeroCoefs is not None and coefficients.nnz >= nbNonzeroCoefs:
+                    converged = True
+                    break
+                if toleranceSnr is not None and snr >= toleranceSnr:
+                    converged = True
+                    break
+                if np.abs(lastEnergyResidual - energyResidual) < eps:             # :1379-1383
+                    logger.warning('Residual energy is no more reduced: considering convergence is achieved')
+                    converged = True
+                    break
+
+            if toleranceResidualScale is not None and np.max(np.abs(residual)) <= toleranceResidualScale:
+                converged = True
+            if len(atoms) == 0:
+                logger.warning('Selection returned empty set: considering convergence is achieved')
+                converged = True
+            if stopCondition is not None and stopCondition(coefficients):         # single-argument form, :1397
+                converged = True
+            offset = not offset
+
+        if minCoefficients is not None:                                           # :1411-1417
+            cx = coefficients.tocoo()
+            keep = np.abs(cx.data) >= minCoefficients
+            clipped = scipy.sparse.lil_matrix((sequence.shape[0], D.shape[0]))
+            clipped[cx.row[keep], cx.col[keep]] = cx.data[keep]
+            coefficients = clipped
+        coefficients = coefficients.tocsc()
+        coefficients.eliminate_zeros()
+        if squeezeOutput:
+            residual = np.squeeze(residual, axis=1)
+        return coefficients, residual

@@ -312,4 +312,7 @@ def __getattr__(name):
     if name in ('HierarchicalConvolutionalMatchingPursuit', 'HierarchicalConvolutionalSparseCoder'):
         from . import hierarchical
         return getattr(hierarchical, name)
+    if name == 'LoCOMP':
+        from . import locomp
+        return locomp.LoCOMP
     raise AttributeError('module %r has no attribute %r' % (__name__, name))

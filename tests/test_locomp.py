@@ -1,0 +1,95 @@
+"""LoCOMP (hsc/modeling.py:1191-1425) against golden vectors of the real reference.
+
+CPU tests replace the three GPU-backed hooks by the CPU oracle (test infrastructure) and check the
+host loop: neighbour search, joint least-squares re-fit, stop rules.  -m gpu tests run the product
+path (hooks through the C ABI).  LoCOMP re-fits coefficients through a pseudo-inverse, so values are
+compared with a tolerance (the reference's own LoCOMP tests use atol=1e-1); the support must match."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+
+def _case(name):
+    z = gu.load('locomp_small.npz')
+    kw = {}
+    for key in ('nbNonzeroCoefs', 'toleranceSnr', 'minCoefficients'):
+        full = '%s__%s' % (name, key)
+        if full in z:
+            kw[key] = int(z[full]) if key == 'nbNonzeroCoefs' else float(z[full])
+    if name + '__nbBlocks' in z:
+        nb = int(z[name + '__nbBlocks'])
+        kw['nbBlocks'] = 'auto' if nb == -1 else nb
+    if name + '__weights' in z:
+        kw['weights'] = z[name + '__weights']
+    exp = dict(residual=z[name + '__residual'], row=z[name + '__csc_row'], col=z[name + '__csc_col'], data=z[name + '__csc_data'])
+    return z[name + '__x'], z[name + '__D'], kw, exp
+
+
+def _names():
+    return [str(n) for n in gu.load('locomp_small.npz')['names']]
+
+
+def _check(coder, name):
+    x, D, kw, exp = _case(name)
+    coefficients, residual = coder.computeCoefficients(x, D, **kw)
+    row, col, data = gu.csc_triplets(coefficients)
+    assert np.array_equal(row, exp['row']) and np.array_equal(col, exp['col']), 'support differs from the reference'
+    tol = 2e-4 if np.result_type(x.dtype, D.dtype) == np.float32 else 1e-8
+    assert float(np.max(np.abs(data - exp['data']))) <= tol * max(1.0, float(np.max(np.abs(exp['data']))))
+    assert residual.shape == exp['residual'].shape and residual.dtype == exp['residual'].dtype
+    assert float(np.max(np.abs(residual.astype(np.float64) - exp['residual']))) <= 10 * tol
+
+
+class _OracleHooks(object):
+    """Mixin replacing the GPU-backed hooks by the CPU oracle."""
+
+    def _selectBestAtoms(self, innerProducts, filterWidth, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
+        from oracle import hsc_oracle as orc
+        from hsc_amd.modeling import Atom
+        t, k, c = orc.select_best_atoms(innerProducts, filterWidth, nbBlocks, offset, nullCoeffThres, weights)
+        return [Atom(int(p), int(f), cc, filterWidth) for p, f, cc in zip(t, k, c)]
+
+    def _updateInnerProducts(self, innerProducts, residual, atoms, D):
+        from oracle import hsc_oracle as orc
+        for a in atoms:
+            orc.update_inner_products(innerProducts, residual, D, a.position)
+        return innerProducts
+
+
+@pytest.mark.parametrize('name', _names())
+def test_locomp_host_loop_with_oracle_hooks(name, monkeypatch):
+    from oracle import hsc_oracle as orc
+    import hsc_amd.locomp as locomp
+
+    class OracleLoCOMP(_OracleHooks, locomp.LoCOMP):
+        pass
+
+    monkeypatch.setattr(locomp, 'convolve1d', lambda seq, D, padding='valid', device=0: orc.convolve1d(seq, D, padding=padding))
+    _check(OracleLoCOMP(), name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', _names())
+def test_locomp_gpu_vs_reference_golden(name):
+    from hsc_amd.modeling import LoCOMP
+    _check(LoCOMP(), name)
+
+
+@pytest.mark.gpu
+def test_hierarchical_default_method_is_locomp():
+    """HierarchicalConvolutionalMatchingPursuit() defaults to method='locomp' (modeling.py:1429):
+    3-level encode against the reference's golden output (case 'd')."""
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, HierarchicalConvolutionalSparseCoder
+    from test_hierarchical import _mld, _golden
+    z = _golden()
+    hcmp = HierarchicalConvolutionalMatchingPursuit()
+    assert hcmp.method == 'locomp'
+    hcsc = HierarchicalConvolutionalSparseCoder(_mld(), hcmp)
+    coefficients, residual = hcsc.encode(z['x'], toleranceSnr=[10.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.5)
+    assert len(coefficients) == 3
+    for l, c in enumerate(coefficients):
+        row, col, data = gu.csc_triplets(c)
+        assert np.array_equal(row, z['case_d__level%d_row' % l]) and np.array_equal(col, z['case_d__level%d_col' % l])
+        assert float(np.max(np.abs(data - z['case_d__level%d_data' % l]))) <= 2e-4
+    assert float(np.max(np.abs(residual - z['case_d__residual']))) <= 1e-4

@@ -12,6 +12,7 @@ Files written:
                                    (reflect padding at both edges) on seeded inputs
   tests/golden/cmp_config.npz   -- BASELINE config 1 (T=4096) and 8 full-size config-2 signals
                                    (T=65536, K=256, W=64, L0=256): outputs + input digests
+  tests/golden/locomp_small.npz -- LoCOMP (modeling.py:1191-1425) on small seeded problems
   tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
                                    singleton bases, representations, per-level coefficients, residual
 """
@@ -258,10 +259,11 @@ def gen_hsc():
     out['x'] = x
     cases = [('a', dict(toleranceSnr=15.0, nbBlocks=1, singletonWeight=0.9)),
              ('b', dict(toleranceSnr=[20.0, 25.0, 30.0], nbBlocks=4, singletonWeight=0.5, returnDistributed=False)),
-             ('c', dict(toleranceSnr=[10.0, 40.0, 40.0], nbBlocks='auto', singletonWeight=0.95))]
+             ('c', dict(toleranceSnr=[10.0, 40.0, 40.0], nbBlocks='auto', singletonWeight=0.95)),
+             ('d', dict(toleranceSnr=[10.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.5))]      # d: method='locomp'
     names = []
     for name, kw in cases:
-        hcmp = ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='cmp')
+        hcmp = ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='locomp' if name == 'd' else 'cmp')
         hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mld, hcmp)
         coefficients, residual = hcsc.encode(x, **kw)
         names.append(name)
@@ -281,9 +283,65 @@ def gen_hsc():
                                     singletonWeight=kw['singletonWeight'], returnDistributed=kw.get('returnDistributed', True))
         for l, c in enumerate(cont):
             pack_csc('case_%s__fromlevel%d' % (name, l), scipy_sparse(c), out)
+        if name == 'a':
+            # events wire format (dataset.py:798-824) of the distributed coefficients
+            ev = ref.dataset.convertSparseMatricesToEvents(coefficients)
+            out['case_a__events_t'] = ev['f0']; out['case_a__events_l'] = ev['f1']
+            out['case_a__events_i'] = ev['f2']; out['case_a__events_c'] = ev['f3']
+            back = ref.dataset.convertEventsToSparseMatrices(ev, [c.shape[1] for c in coefficients], coefficients[0].shape[0])
+            for l, bm in enumerate(back):
+                pack_csc('case_a__back%d' % l, bm, out)
     out['names'] = np.array(names)
     np.savez_compressed(os.path.join(OUT, 'hsc_small.npz'), **out)
     print('hsc_small.npz: %d cases' % len(names))
+
+
+def gen_locomp():
+    """LoCOMP (modeling.py:1191-1425) on small seeded problems."""
+    ref = load_reference()
+    norm = ref.utils.normalize
+    rs = np.random.RandomState(1357)
+    out = {}
+    names = []
+
+    def planted(D, T, events):
+        x = np.zeros((T,) + D.shape[2:], dtype=np.float64)
+        for c, p, k in events:
+            s, e, es, ee = synth.centered_span(T, D.shape[1], p)
+            x[s:e] += c * D[k][es:ee]
+        return x
+
+    cases = []
+    ev = list(zip([1.0, 1.0, 0.5, 1.0, 0.75, 2.0], [32, 48, 64, 96, 128, 192], [0, 3, 1, 0, 2, 2]))
+    for dt, tag in ((np.float64, 'f64'), (np.float32, 'f32')):
+        D = norm(rs.random_sample((4, 32)).astype(dt), axis=1)
+        cases.append(('%s_planted_1d' % tag, planted(D, 256, ev).astype(dt), D, dict(minCoefficients=1e-10)))
+        D3 = norm(rs.random_sample((4, 32, 7)).astype(dt), axis=(1, 2))
+        cases.append(('%s_planted_2d' % tag, planted(D3, 256, ev).astype(dt), D3, dict(minCoefficients=1e-10)))
+        D = norm(rs.standard_normal((16, 15)).astype(dt), axis=1)
+        x = rs.standard_normal(256).astype(dt)
+        for nb in (1, 2, 8, 'auto'):
+            cases.append(('%s_T256_K16_W15_snr5_nb%s' % (tag, nb), x, D, dict(toleranceSnr=5.0, nbBlocks=nb)))
+        cases.append(('%s_T256_K16_W15_L12' % tag, x, D, dict(nbNonzeroCoefs=12)))
+        w = np.ones(16, dtype=dt); w[:4] = 0.5
+        cases.append(('%s_T256_K16_W15_snr8_weights' % tag, x, D, dict(toleranceSnr=8.0, nbBlocks=4, weights=w)))
+    for name, x, D, kw in cases:
+        coefficients, residual = ref.modeling.LoCOMP().computeCoefficients(x, D, **kw)
+        names.append(name)
+        out[name + '__x'] = x
+        out[name + '__D'] = D
+        for key, val in kw.items():
+            if key == 'weights':
+                out[name + '__weights'] = val
+            elif key == 'nbBlocks':
+                out[name + '__nbBlocks'] = np.array(-1 if val == 'auto' else val)
+            else:
+                out[name + '__' + key] = np.array(val)
+        out[name + '__residual'] = residual
+        pack_csc(name + '__csc', coefficients, out)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'locomp_small.npz'), **out)
+    print('locomp_small.npz: %d cases' % len(names))
 
 
 def scipy_sparse(c):
@@ -294,7 +352,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -303,3 +361,5 @@ if __name__ == '__main__':
         gen_config()
     if 'hsc' in which:
         gen_hsc()
+    if 'locomp' in which:
+        gen_locomp()
