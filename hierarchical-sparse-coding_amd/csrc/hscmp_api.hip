@@ -168,10 +168,16 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
         HIP_TRY(ctx, hipMemcpy(ctx->d_Dt, dt.data(), nD, hipMemcpyHostToDevice));
     }
     // MFMA operand image of the dictionary (f32 only): built once, reused by every encode
-    if (dtype == HSCMP_F32 && mfma_supported(K, W, F)) {
+    if (dtype == HSCMP_F32 && mfma_supported<float>(K, W, F)) {
         std::vector<float> frag;
         mfma_build_dict_image((const float*)D, K, W, F, frag);
         ctx->Dfrag_bytes = frag.size() * sizeof(float);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Dfrag, ctx->Dfrag_bytes));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Dfrag, frag.data(), ctx->Dfrag_bytes, hipMemcpyHostToDevice));
+    } else if (dtype == HSCMP_F64 && mfma_supported<double>(K, W, F)) {
+        std::vector<double> frag;
+        mfma_build_dict_image_f64((const double*)D, K, W, frag);
+        ctx->Dfrag_bytes = frag.size() * sizeof(double);
         HIP_TRY(ctx, hipMalloc(&ctx->d_Dfrag, ctx->Dfrag_bytes));
         HIP_TRY(ctx, hipMemcpy(ctx->d_Dfrag, frag.data(), ctx->Dfrag_bytes, hipMemcpyHostToDevice));
     }
@@ -264,7 +270,7 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
 {
     if (getenv("HSCMP_FORCE_GENERIC")) return false;
     // the score-only MFMA path assumes single-bounce reflection at the edges (T >= 3W-2)
-    return ctx->dtype == HSCMP_F32 && ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
+    return ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
 // Loop policy for multi-feature inputs (hierarchical levels >= 1): SparseRecorr gathers the non-zeros
@@ -329,8 +335,8 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     bool mf = false;
-    if (sizeof(R) == 4 && use_mfma(ctx, P.T)) {
-        int rc = mfma_launch_corr_init(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
+    if (use_mfma(ctx, P.T)) {
+        int rc = mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
         if (rc == 0) mf = true;
     }
     const bool spi = !mf && use_sparse_init(ctx, P.T);
@@ -342,8 +348,8 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     bool mfi = false;
-    if (sizeof(R) == 4 && use_mfma(ctx, P.T)) {
-        int rc = mfma_launch_iterate(ctx->stream, P, *(State<float>*)&S, (const float*)ctx->d_Dfrag);
+    if (use_mfma(ctx, P.T)) {
+        int rc = mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
         if (rc == 0) mfi = true;
     }
     const bool spl = !mfi && use_sparse_loop(ctx);
@@ -398,9 +404,14 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
     DevParams P = ctx->P;
     P.max_rounds = max_rounds;
     bool mfi = false;
-    if (ctx->dtype == HSCMP_F32 && use_mfma(ctx, P.T)) {
-        State<float> S = make_state<float>(ctx);
-        if (mfma_launch_iterate(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
+    if (use_mfma(ctx, P.T)) {
+        if (ctx->dtype == HSCMP_F32) {
+            State<float> S = make_state<float>(ctx);
+            if (mfma_launch_iterate<float>(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
+        } else {
+            State<double> S = make_state<double>(ctx);
+            if (mfma_launch_iterate<double>(ctx->stream, P, S, (const double*)ctx->d_Dfrag) == 0) mfi = true;
+        }
     }
     if (!mfi && use_sparse_loop(ctx)) {
         int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);

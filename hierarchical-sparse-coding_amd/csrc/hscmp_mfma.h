@@ -33,27 +33,22 @@ namespace hscmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMfmaMaxSeg = 512;          // smaller control block: leaves LDS for the dictionary image
 constexpr int kMfmaChunk = 2048;          // positions per workgroup of the initial correlation
-constexpr size_t kMfmaMaxDictBytes = 64 * 1024;
 
-struct MfmaArgs {
-    const float* dimg;   // device dictionary image
-    int G;               // atom groups of 32
-    int S4;              // chunks of 4 k-steps (8 taps)
+template <typename R> struct MfmaArgsT {
+    const R* dimg;       // device dictionary image
+    int G;               // atom groups (32 atoms for float32, 16 for float64)
+    int S4;              // chunks of 8 taps (one 16-byte A-operand word per lane)
     int has_w;
 };
+using MfmaArgs = MfmaArgsT<float>;
 
 inline int mfma_groups(int K) { return (K + 31) / 32; }
 inline int mfma_chunks(int W) { return (W + 7) / 8; }
-
-inline bool mfma_supported(int K, int W, int F)
-{
-    if (F != 1) return false;   // (per launch, T >= 3W-2 is required as well: see mfma_shape_ok)
-    const size_t bytes = (size_t)mfma_groups(K) * mfma_chunks(W) * 64 * 4 * sizeof(float);
-    return bytes <= kMfmaMaxDictBytes && W <= 128;
-}
 
 // host: Dimg[g][s4][lane][q] = D[32g + (lane&31)][2*(4*s4+q) + (lane>>5)], zero padded
 inline void mfma_build_dict_image(const float* D, int K, int W, int F, std::vector<float>& out)
@@ -212,12 +207,12 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
     return fmaxf(bs, swap_halves_f(bs, h));
 }
 
-__device__ __forceinline__ void lds_copy_f32(float* dst, const float* __restrict__ src, int n)
+__device__ __forceinline__ void lds_copy16(void* dst, const void* __restrict__ src, int nbytes)
 {
-    // n is a multiple of 4; 16-byte coalesced copy, 8 loads in flight per thread before the stores
+    // nbytes is a multiple of 16; coalesced copy, 8 loads in flight per thread before the stores
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    const int n4 = n / 4;
+    const int n4 = nbytes / 16;
     for (int base = 0; base < n4; base += 8 * kThreads) {
         f32x4 v[8];
 #pragma unroll
@@ -243,33 +238,35 @@ __device__ __forceinline__ void lds_copy_f32(float* dst, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int kMfmaChunkLoads = (kMfmaChunk + 128 + 32 + kThreads - 1) / kThreads;   // chunk + max taps (W<=128) + slack
 
-template <int S4C, bool HAS_W>
-__global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, State<float> S, MfmaArgs A)
+template <typename Tile, int S4C, bool HAS_W>
+__global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, State<typename Tile::R> S, MfmaArgsT<typename Tile::R> A)
 {
+    using R = typename Tile::R;
+    constexpr int TP = Tile::TP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int G = A.G, S4 = S4C > 0 ? S4C : A.S4;
-    const int nd = G * S4 * 256;                        // floats in the dictionary image
-    float* dimg = reinterpret_cast<float*>(smem);
-    float* wts = dimg + nd;
-    float* xs = wts + 32 * G;
+    const int nd = G * S4 * Tile::kChunkElems;          // elements of the dictionary image
+    R* dimg = reinterpret_cast<R*>(smem);
+    R* wts = dimg + nd;
+    R* xs = wts + Tile::GA * G;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = P.T;
     const int nx = kMfmaChunk + 8 * S4 + 32;            // chunk + taps + slack for the last tile's kk offset
     const int cps = (T + kMfmaChunk - 1) / kMfmaChunk;  // chunks per signal
     const int nitems = cps * P.B;
 
-    lds_copy_f32(dimg, A.dimg, nd);
-    if (HAS_W) for (int i = tid; i < 32 * G; i += kThreads) wts[i] = i < P.K ? S.weights[i] : 0.0f;
+    lds_copy16(dimg, A.dimg, nd * (int)sizeof(R));
+    if (HAS_W) for (int i = tid; i < Tile::GA * G; i += kThreads) wts[i] = i < P.K ? S.weights[i] : (R)0;
 
-    float xr[kMfmaChunkLoads];
+    R xr[kMfmaChunkLoads];
     auto fetch = [&](int item) {                        // global -> registers (zero padding of 'same', :159-164)
         const int b = item / cps, c0 = (item % cps) * kMfmaChunk;
-        const float* x = S.residual + (int64_t)b * T;   // residual == copy of the signal at this point
+        const R* x = S.residual + (int64_t)b * T;       // residual == copy of the signal at this point
 #pragma unroll
         for (int u = 0; u < kMfmaChunkLoads; ++u) {
             const int i = u * kThreads + tid;
             const int g = c0 - P.off + i;
-            xr[u] = (i < nx && g >= 0 && g < T) ? x[g] : 0.0f;
+            xr[u] = (i < nx && g >= 0 && g < T) ? x[g] : (R)0;
         }
     };
     auto stash = [&]() {                                // registers -> LDS
@@ -289,24 +286,29 @@ __global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, S
         if (next < nitems) fetch(next);                 // in flight while this chunk is computed
         const int b = item / cps, c0 = (item % cps) * kMfmaChunk;
         const int npos = min(kMfmaChunk, T - c0);
-        const int ntiles = (npos + 31) / 32;
+        const int ntiles = (npos + TP - 1) / TP;
         for (int q = wv; q < ntiles; q += kWaves) {
-            const float sc = mfma_tile_score<S4C, HAS_W>(dimg, xs + 32 * q, wts, G, S4, lane);
-            const int t = c0 + 32 * q + lane;
-            if (lane < 32 && t < T) S.best_c[(int64_t)b * T + t] = sc;      // score-only state (see mfma_tile_score)
+            const R sc = Tile::template tile_score<S4C, HAS_W>(dimg, xs + TP * q, wts, G, S4, lane);
+            const int t = c0 + TP * q + lane;
+            if (lane < TP && t < T) S.best_c[(int64_t)b * T + t] = sc;      // score-only state (see mfma_tile_score)
         }
         __syncthreads();                                // all tiles read xs before it is overwritten
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// MfmaRecorr: policy of iterate_kernel.  It owns the whole per-atom body (kFused): the greedy loop
-// is a chain of DEPENDENT steps, so what bounds it besides the MFMA work is the number of global
-// memory round trips and barriers per applied atom.  apply_atom() issues every global load of an
-// atom in ONE batch (residual span, the old per-position best of the touched segments, the slot
-// keys for the duplicate scan), does everything else out of LDS, and needs three barriers.
-// Policy LDS: [dictionary image][weights][residual window][squares][touched-segment buffers]
-// ------------------------------------------------------------------------------------------------
+// value held by lane `src` (wave-uniform index) in every lane: v_readlane, no LDS crossbar
+__device__ __forceinline__ float wave_bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (long long)lo);
+}
+
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
 // outstanding global stores (vmcnt), which costs a full memory round trip per barrier
 __device__ __forceinline__ void lds_barrier()
@@ -368,11 +370,12 @@ __device__ __forceinline__ float resolve_chain(const float* __restrict__ dimg, c
 // sample.  Outside: the initial table is ZERO padded (modeling.py:159-164) but every local update
 // REFLECT pads (modeling.py:1046), so a row that has been re-correlated at least once (edge bit set)
 // sees r reflected about 0 / T-1, an untouched one sees 0.  (T >= 3W-2 on this path: one bounce.)
-__device__ __forceinline__ float edge_window_value(const float* __restrict__ r, int T, int g, int p, const unsigned long long* edge)
+template <typename R>
+__device__ __forceinline__ R edge_window_value(const R* __restrict__ r, int T, int g, int p, const unsigned long long* edge)
 {
     if (g >= 0 && g < T) return r[g];
-    if (g < 0) return ((edge[0] >> p) & 1ull) ? r[-g] : 0.0f;
-    return ((edge[1] >> (T - 1 - p)) & 1ull) ? r[2 * (T - 1) - g] : 0.0f;
+    if (g < 0) return ((edge[0] >> p) & 1ull) ? r[-g] : (R)0;
+    return ((edge[1] >> (T - 1 - p)) & 1ull) ? r[2 * (T - 1) - g] : (R)0;
 }
 
 __device__ __forceinline__ unsigned long long bit_range(int a, int b)     // bits a..b (0 <= a <= b <= 63)
@@ -381,56 +384,226 @@ __device__ __forceinline__ unsigned long long bit_range(int a, int b)     // bit
     return hi & ~((1ull << a) - 1ull);
 }
 
-template <int S4C, bool HAS_W> struct MfmaRecorr {
+// ================================================================================================
+// float64 tile: v_mfma_f64_16x16x4_f64 -- [16 atoms] x [16 positions], 4 taps per MFMA.  Measured
+// (tools/mfma_f64_probe.hip): bit-exact k-ordered fma chain like the f32 form, 57-70 TFLOP/s.
+//   A[i][kk] = D[atom0+i][4s+kk]  (lane l: i = l&15, kk = l>>4)     B[kk][j] = win[pos0+j + 4s+kk]
+//   C/D: 4 doubles per lane, col = l&15 (position), row = (l>>4) + 4*reg (atom)
+// Image Dimg64[g][c][lane][2]: group g of 16 atoms, chunk c of 8 taps = two k-steps per 16-byte word.
+// ================================================================================================
+inline void mfma_build_dict_image_f64(const double* D, int K, int W, std::vector<double>& out)
+{
+    const int G = (K + 15) / 16, S4 = mfma_chunks(W);
+    out.assign((size_t)G * S4 * 64 * 2, 0.0);
+    for (int g = 0; g < G; ++g)
+        for (int c = 0; c < S4; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 2; ++e) {
+                    const int k = 16 * g + (lane & 15);
+                    const int w = 8 * c + 4 * e + (lane >> 4);
+                    if (k < K && w < W) out[(((size_t)g * S4 + c) * 64 + lane) * 2 + e] = D[(size_t)k * W + w];
+                }
+}
+
+__device__ __forceinline__ int dimg_index_f64(int k, int w, int S4)
+{
+    const int r8 = w & 7;
+    return ((((k >> 4) * S4 + (w >> 3)) * 64 + (k & 15) + 16 * (r8 & 3)) * 2) + (r8 >> 2);
+}
+
+template <int S4C>
+__device__ __forceinline__ double resolve_chain_f64(const double* __restrict__ dimg, const double* __restrict__ rwin, int k, int S4rt)
+{
+    const int S4 = S4C > 0 ? S4C : S4rt;
+    const f64x2* dv = reinterpret_cast<const f64x2*>(dimg) + ((k >> 4) * S4) * 64 + (k & 15);
+    const f64x2* rw = reinterpret_cast<const f64x2*>(rwin);
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < (S4C > 0 ? S4C : S4); ++c) {
+        const f64x2 q0 = dv[c * 64], q1 = dv[c * 64 + 16], q2 = dv[c * 64 + 32], q3 = dv[c * 64 + 48];
+        const f64x2 r0 = rw[4 * c], r1 = rw[4 * c + 1], r2 = rw[4 * c + 2], r3 = rw[4 * c + 3];
+        acc = fma(r0[0], q0[0], acc);      // taps 8c+0 .. 8c+3: k-step 2c, kk = 0..3
+        acc = fma(r0[1], q1[0], acc);
+        acc = fma(r1[0], q2[0], acc);
+        acc = fma(r1[1], q3[0], acc);
+        acc = fma(r2[0], q0[1], acc);      // taps 8c+4 .. 8c+7: k-step 2c+1
+        acc = fma(r2[1], q1[1], acc);
+        acc = fma(r3[0], q2[1], acc);
+        acc = fma(r3[1], q3[1], acc);
+    }
+    return acc;
+}
+
+template <int S4C, bool HAS_W>
+__device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__ dimg, const double* __restrict__ win,
+                                                      const double* __restrict__ wts, int G, int S4rt, int lane)
+{
+    const int j = lane & 15, kk = lane >> 4;
+    const double* wb = win + j + kk;
+    double bs = 0.0;
+    const f64x2* dv = reinterpret_cast<const f64x2*>(dimg) + lane;
+    auto reduce_elem = [&](double v, int k) {
+        if (HAS_W) v = v * wts[k];
+        bs = fmax(bs, fabs(v));
+    };
+    if constexpr (S4C > 0) {
+        constexpr int NM = 2 * S4C;            // MFMAs per atom group
+        double bop[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) bop[m] = wb[4 * m];
+        f64x2 a0[S4C], a1[S4C];
+        f64x4 acc0, acc1;
+        auto load_a = [&](f64x2 (&a)[S4C], int g) {
+#pragma unroll
+            for (int c = 0; c < S4C; ++c) a[c] = dv[(g * S4C + c) * 64];
+        };
+        auto run_first = [&](const f64x2 (&a)[S4C], f64x4& acc) {
+            acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m >> 1][m & 1], bop[m], acc, 0, 0, 0);
+        };
+        auto run_next = [&](const f64x2 (&a)[S4C], f64x4& acc, const f64x4& accp, int kbasep) {
+            acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m >> 1][m & 1], bop[m], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = (m * 4) / NM; e < ((m + 1) * 4) / NM; ++e) reduce_elem(accp[e], kbasep + 4 * e);
+            }
+        };
+        auto reduce_all = [&](const f64x4& acc, int kbase) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reduce_elem(acc[e], kbase + 4 * e);
+        };
+        load_a(a0, 0);
+        if (G > 1) load_a(a1, 1);
+        run_first(a0, acc0);
+        int g = 1;
+        for (; g + 1 < G; g += 2) {
+            load_a(a0, g + 1);
+            run_next(a1, acc1, acc0, 16 * (g - 1) + kk);
+            if (g + 2 < G) load_a(a1, g + 2);
+            run_next(a0, acc0, acc1, 16 * g + kk);
+        }
+        if (g < G) {
+            run_next(a1, acc1, acc0, 16 * (g - 1) + kk);
+            reduce_all(acc1, 16 * g + kk);
+        } else {
+            reduce_all(acc0, 16 * (G - 1) + kk);
+        }
+    } else {
+        const int S4 = S4rt;
+        for (int g = 0; g < G; ++g) {
+            f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < S4; ++c) {
+                const f64x2 a = dv[(g * S4 + c) * 64];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], wb[8 * c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], wb[8 * c + 4], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reduce_elem(acc[e], 16 * g + kk + 4 * e);
+        }
+    }
+    // the four 16-lane quarters hold the same position with interleaved atom sets
+    bs = fmax(bs, __shfl_xor(bs, 16));
+    bs = fmax(bs, __shfl_xor(bs, 32));
+    return bs;
+}
+
+// ---- tile traits: what the kernels below need to know about the two MFMA shapes ----------------
+struct TileF32 {
+    using R = float;
+    static constexpr int TP = 32;                       // positions per tile
+    static constexpr int GA = 32;                       // atoms per group
+    static constexpr int kChunkElems = 256;             // image elements per (group, chunk): 64 lanes x 16 bytes
+    static constexpr size_t kMaxImageBytes = 64 * 1024; // two workgroups per CU
+    static int groups(int K) { return (K + 31) / 32; }
+    template <int S4C, bool HAS_W>
+    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
+    { return mfma_tile_score<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
+    { return resolve_chain<S4C>(dimg, rwin, k, S4); }
+    static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index(k, w, S4); }
+};
+struct TileF64 {
+    using R = double;
+    static constexpr int TP = 16;
+    static constexpr int GA = 16;
+    static constexpr int kChunkElems = 128;
+    static constexpr size_t kMaxImageBytes = 128 * 1024; // one workgroup per CU
+    static int groups(int K) { return (K + 15) / 16; }
+    template <int S4C, bool HAS_W>
+    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
+    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
+    { return resolve_chain_f64<S4C>(dimg, rwin, k, S4); }
+    static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index_f64(k, w, S4); }
+};
+template <typename R> struct TileOf;
+template <> struct TileOf<float> { using type = TileF32; };
+template <> struct TileOf<double> { using type = TileF64; };
+
+template <typename R> inline bool mfma_supported(int K, int W, int F)
+{
+    using Tile = typename TileOf<R>::type;
+    if (F != 1) return false;   // (per launch, T >= 3W-2 is required as well)
+    const size_t bytes = (size_t)Tile::groups(K) * mfma_chunks(W) * Tile::kChunkElems * sizeof(R);
+    return bytes <= Tile::kMaxImageBytes && W <= 128;
+}
+
+template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
     static constexpr bool kScoreOnly = true;    // best_c[t] holds max_k |c[t,k]*w_k|; (k, c) resolved on selection
     static constexpr int kBook = 192;           // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
-    using Shared = IterSharedT<float, kMfmaMaxSeg, false, false>;
-    using Args = MfmaArgs;
+    using R = typename Tile::R;
+    static constexpr int TP = Tile::TP;
+    using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
+    using Args = MfmaArgsT<R>;
 
     struct Layout {
-        float* dimg; float* wts; float* win; float* esq; float* sbs; unsigned* bloom;
-        float* rwin; float* rwin_w; unsigned long long* edge;
+        R* dimg; R* wts; R* win; R* esq; R* sbs; unsigned* bloom;
+        R* rwin; R* rwin_w; unsigned long long* edge;
         int nwin, wp, nsbmax;
     };
 
-    static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + 31) / 32) * 32 + 8 * S4 + 32; }
+    static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + TP - 1) / TP) * TP + 8 * S4 + 32; }
     static __host__ __device__ int segbuf_len(int W, int seg) { return ((2 * W - 2) / seg + 2) * seg; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A)
     {
-        return ((size_t)A.G * A.S4 * 256 + (HAS_W ? 32 * A.G : 0) + window_floats(P.W, A.S4) + 2 * 8 * A.S4 +
-                (size_t)segbuf_len(P.W, P.seg) + kBloomWords + 8 * A.S4 + kWaves * 8 * A.S4 + 4) * sizeof(float);
+        const size_t relems = (size_t)A.G * A.S4 * Tile::kChunkElems + (HAS_W ? Tile::GA * A.G : 0) + window_floats(P.W, A.S4) +
+                              2 * 8 * A.S4 + (size_t)segbuf_len(P.W, P.seg) + 8 * A.S4 + kWaves * 8 * A.S4;
+        return relems * sizeof(R) + kBloomWords * sizeof(unsigned) + 2 * sizeof(unsigned long long);
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
         const int S4 = S4C > 0 ? S4C : A.S4;
         Layout L;
-        L.dimg = reinterpret_cast<float*>(lds);
-        L.wts = L.dimg + A.G * S4 * 256;
+        L.dimg = reinterpret_cast<R*>(lds);
+        L.wts = L.dimg + A.G * S4 * Tile::kChunkElems;
         L.nwin = window_floats(P.W, S4);
         L.wp = 8 * S4;
         L.nsbmax = segbuf_len(P.W, P.seg);
-        L.win = L.wts + (HAS_W ? 32 * A.G : 0);
+        L.win = L.wts + (HAS_W ? Tile::GA * A.G : 0);
         L.esq = L.win + L.nwin;
         L.sbs = L.esq + 2 * L.wp;
         L.bloom = reinterpret_cast<unsigned*>(L.sbs + L.nsbmax);
-        L.rwin = reinterpret_cast<float*>(L.bloom + kBloomWords);
+        L.rwin = reinterpret_cast<R*>(L.bloom + kBloomWords);
         L.rwin_w = L.rwin + L.wp;
         L.edge = reinterpret_cast<unsigned long long*>(L.rwin_w + kWaves * L.wp);
         return L;
     }
 
-    static __device__ __forceinline__ void prologue(const DevParams& P, const State<float>& S, const Args& A, char* lds)
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds)
     {
         const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
         const int b = blockIdx.x;
-        lds_copy_f32(L.dimg, A.dimg, A.G * S4 * 256);
-        if (HAS_W) for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : 0.0f;
-        for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = 0.0f;   // the tail behind the span stays zero
+        lds_copy16(L.dimg, A.dimg, A.G * S4 * Tile::kChunkElems * (int)sizeof(R));
+        if (HAS_W) for (int i = threadIdx.x; i < Tile::GA * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : (R)0;
+        for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = (R)0;   // the tail behind the span stays zero
         for (int i = threadIdx.x; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
-        for (int i = threadIdx.x; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = 0.0f;   // padded taps stay zero
+        for (int i = threadIdx.x; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = (R)0;   // padded taps stay zero
         if (threadIdx.x < 2) L.edge[threadIdx.x] = S.edge[2 * b + threadIdx.x];
         __syncthreads();
         // resumed launch: re-enter the (t,k) pairs selected so far
@@ -444,7 +617,7 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         // visibility: the caller's next __syncthreads()
     }
 
-    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<float>& S, const Args& A, char* lds)
+    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>& S, const Args& A, char* lds)
     {
         const Layout L = layout(P, A, lds);
         if (threadIdx.x < 2) S.edge[2 * blockIdx.x + threadIdx.x] = L.edge[threadIdx.x];
@@ -452,31 +625,31 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
 
     // never reached: iterate_kernel hands the whole atom body to apply_atom() when kFused
     template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams&, const State<float>&, const Sig<float>&, SH&, const Args&, char*, int) {}
+    static __device__ __forceinline__ void run(const DevParams&, const State<R>&, const Sig<R>&, SH&, const Args&, char*, int) {}
 
     // (k, c) of position t by ONE wave (blocked selection, modeling.py:935-946): the window goes to
     // this wave's private LDS strip, lanes stride over the atoms, first k wins ties.
-    static __device__ __forceinline__ void resolve_wave(const DevParams& P, const State<float>&, const Sig<float>& Gs,
-                                                        const Args& A, char* lds, int t, int lane, int& k_out, float& c_out)
+    static __device__ __forceinline__ void resolve_wave(const DevParams& P, const State<R>&, const Sig<R>& Gs,
+                                                        const Args& A, char* lds, int t, int lane, int& k_out, R& c_out)
     {
         const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
-        float* rw = L.rwin_w + (threadIdx.x >> 6) * L.wp;
+        R* rw = L.rwin_w + (threadIdx.x >> 6) * L.wp;
         __builtin_amdgcn_wave_barrier();
         for (int w = lane; w < P.W; w += 64) rw[w] = edge_window_value(Gs.r, P.T, t - P.off + w, t, L.edge);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
-        float bc = 0.0f;
+        Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+        R bc = (R)0;
         for (int k = lane; k < P.K; k += 64) {
-            const float acc = resolve_chain<S4C>(L.dimg, rw, k, S4);
-            float sc;
-            if (HAS_W) { const float sw = acc * L.wts[k]; sc = fabsf(sw); } else sc = fabsf(acc);
+            const R acc = Tile::template resolve<S4C>(L.dimg, rw, k, S4);
+            R sc;
+            if (HAS_W) { const R sw = acc * L.wts[k]; sc = rabs(sw); } else sc = rabs(acc);
             if (sc > best.s) { best.s = sc; best.i = k; bc = acc; }
         }
         best = wave_argmax(best);
         k_out = best.i;
-        c_out = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc), best.i & 63));
+        c_out = wave_bcast(bc, best.i & 63);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -485,8 +658,8 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
     // selection); otherwise they are resolved here and the null test of :974 is applied.
     // Returns true when the atom loop must stop.
     template <typename SH>
-    static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<float>& S, const Sig<float>& Gs,
-                                                      SH& sh, const Args& A, char* lds, int p, int k, float c, bool resolved)
+    static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<R>& S, const Sig<R>& Gs,
+                                                      SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved)
     {
         (void)S;
         const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -498,7 +671,7 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             return true;
         }
         HSCMP_STAMP_BEGIN();
-        const int nrows = 2 * W - 1, ntiles = (nrows + 31) / 32, span = 3 * W - 2;
+        const int nrows = 2 * W - 1, ntiles = (nrows + TP - 1) / TP, span = 3 * W - 2;
         const int tstart = p - P.off - (W - 1);                 // :1028-1033
         const int tend = p + W / 2 + (W - 1);                   // :1038
         const int sidx = tstart < 0 ? 0 : tstart;               // :1034
@@ -513,21 +686,21 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         const int nsb = min(T, ((sg1 + 1) << P.seg_shift)) - segbase;    // positions of the touched segments
 
         // ---- phase A: every global load of this atom, issued together -------------------------
-        float rv[2]; int rm[2];
+        R rv[2]; int rm[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * kThreads;
-            rm[u] = -1; rv[u] = 0.0f;
+            rm[u] = -1; rv[u] = (R)0;
             if (i < span) {                                     // np.pad 'reflect', :1046 (identity away from the edges)
                 rm[u] = interior ? tstart + i : reflect_index(tstart + i, sidx, nslice);
                 rv[u] = Gs.r[rm[u]];
             }
         }
-        float os[2];
+        R os[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * kThreads;
-            os[u] = 0.0f;
+            os[u] = (R)0;
             if (i < nsb) os[u] = Gs.bc[segbase + i];            // old scores of the touched segments
         }
         if (!resolved) {
@@ -542,19 +715,19 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {
             lds_barrier();                                      // Bx: the position's window is in LDS
-            Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
-            float bc = 0.0f;
+            Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+            R bc = (R)0;
             for (int kk = tid; kk < P.K; kk += kThreads) {
-                const float acc = resolve_chain<S4C>(L.dimg, L.rwin, kk, S4);
-                float sc;
-                if (HAS_W) { const float sw = acc * L.wts[kk]; sc = fabsf(sw); } else sc = fabsf(acc);
+                const R acc = Tile::template resolve<S4C>(L.dimg, L.rwin, kk, S4);
+                R sc;
+                if (HAS_W) { const R sw = acc * L.wts[kk]; sc = rabs(sw); } else sc = rabs(acc);
                 if (sc > best.s) { best.s = sc; best.i = kk; bc = acc; }
             }
-            const Cand<float> wbest = wave_argmax(best);
+            const Cand<R> wbest = wave_argmax(best);
             if (best.i == wbest.i && wbest.i != INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = bc; }   // the owner lane
-            if (lane == 0 && wbest.i == INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = 0.0f; }
+            if (lane == 0 && wbest.i == INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = (R)0; }
             lds_barrier();                                      // By
-            Cand<float> m = sh.cred[0];
+            Cand<R> m = sh.cred[0];
             c = sh.red[0];
 #pragma unroll
             for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) { m = sh.cred[q]; c = sh.red[q]; }
@@ -577,17 +750,17 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         }
 
         // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
-        const float nc = -c;
+        const R nc = -c;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * kThreads;
             if (i < span) {
-                float v = rv[u];
+                R v = rv[u];
                 const int m = rm[u];
                 if (m >= s && m < e) {
                     const int q = m - s;
-                    const float prod = nc * L.dimg[dimg_index(k, es + q, S4)];   // -c*D[k] rounded, then += (utils.py:120,129)
-                    const float vn = v + prod;
+                    const R prod = nc * L.dimg[Tile::dindex(k, es + q, S4)];   // -c*D[k] rounded, then += (utils.py:120,129)
+                    const R vn = v + prod;
                     if (tstart + i == m) {                    // the sample itself (not a reflected copy)
                         Gs.r[m] = vn;
                         L.esq[q] = v * v;
@@ -608,11 +781,11 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         HSCMP_STAMP(1);                                         // B1
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
         {
-            float pb = 0.0f, pa = 0.0f;
+            R pb = (R)0, pa = (R)0;
             if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
-                const float ob = __shfl_down(pb, m), oa = __shfl_down(pa, m);
+                const R ob = __shfl_down(pb, m), oa = __shfl_down(pa, m);
                 pb = pb + ob;
                 pa = pa + oa;
             }
@@ -622,9 +795,9 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
 
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
         for (int q = wv; q < ntiles; q += kWaves) {
-            const float sc = mfma_tile_score<S4C, HAS_W>(L.dimg, L.win + 32 * q, L.wts, A.G, S4, lane);
-            const int row = 32 * q + lane, t = p - (W - 1) + row;
-            if (lane < 32 && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
+            const R sc = Tile::template tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
+            const int row = TP * q + lane, t = p - (W - 1) + row;
+            if (lane < TP && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
                 Gs.bc[t] = sc;
                 L.sbs[t - segbase] = sc;
             }
@@ -636,9 +809,9 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         // ---- maxima of the touched segments, out of LDS
         for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) {
             const int t0 = (sg << P.seg_shift), t1 = min(T, t0 + P.seg);
-            Cand<float> best; best.s = -1.0f; best.i = INT_MAX;
+            Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
             for (int t = t0 + lane; t < t1; t += 64) {
-                const float sc = L.sbs[t - segbase];
+                const R sc = L.sbs[t - segbase];
                 if (sc > best.s) { best.s = sc; best.i = t; }
             }
             best = wave_argmax(best);
@@ -649,16 +822,16 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
         bool new_slot = false;
         double acc_old = 0.0;
         if (tid == kBook) {
-            const float b01 = sh.red[0] + sh.red[1], b23 = sh.red[2] + sh.red[3];
-            const float a01 = sh.red[kWaves + 0] + sh.red[kWaves + 1], a23 = sh.red[kWaves + 2] + sh.red[kWaves + 3];
-            const float e_before = b01 + b23, e_after = a01 + a23;
-            const float loss = e_before - e_after;              // :1005
+            const R b01 = sh.red[0] + sh.red[1], b23 = sh.red[2] + sh.red[3];
+            const R a01 = sh.red[kWaves + 0] + sh.red[kWaves + 1], a23 = sh.red[kWaves + 2] + sh.red[kWaves + 3];
+            const R e_before = b01 + b23, e_after = a01 + a23;
+            const R loss = e_before - e_after;              // :1005
             sh.e_res = sh.e_res - loss;                         // :1014
             si = sh.found;
             sh.found = -1;
             if (si >= 0) { acc_old = Gs.slot_a[si]; }           // rare: re-selection of an existing (t,k)
             if (si >= 0 && fabs(acc_old) > 0.0) sh.ndup += 1;
-            else if (fabsf(c) > 0.0f) sh.nnz += 1;
+            else if (rabs(c) > (R)0) sh.nnz += 1;
             if (si < 0) { new_slot = true; si = sh.nslots++; L.bloom[hb >> 5] |= 1u << (hb & 31); }
             ev = sh.nev++;
             sh.iters += 1;
@@ -669,7 +842,7 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
             if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
             else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
             else if (P.has_snr) {
-                const float qv = sh.e_sig / sh.e_res;
+                const R qv = sh.e_sig / sh.e_res;
                 if ((double)qv >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
             }
         }
@@ -692,11 +865,13 @@ template <int S4C, bool HAS_W> struct MfmaRecorr {
 };
 
 // host-side dispatch -----------------------------------------------------------------------------
-template <int S4C, bool HAS_W>
-static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const State<float>& S, const MfmaArgs& A)
+template <typename Tile, int S4C, bool HAS_W>
+static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const State<typename Tile::R>& S,
+                                   const MfmaArgsT<typename Tile::R>& A)
 {
-    const size_t lds = ((size_t)A.G * A.S4 * 256 + 32 * A.G + kMfmaChunk + 8 * A.S4 + 32) * sizeof(float);
-    auto kern = corr_init_mfma_kernel<S4C, HAS_W>;
+    using R = typename Tile::R;
+    const size_t lds = ((size_t)A.G * A.S4 * Tile::kChunkElems + Tile::GA * A.G + kMfmaChunk + 8 * A.S4 + 32) * sizeof(R);
+    auto kern = corr_init_mfma_kernel<Tile, S4C, HAS_W>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     // persistent grid: as many workgroups as are resident at once (LDS-bound), capped by the work
     static int cus = 0;          // same device family in one process: query once
@@ -717,52 +892,57 @@ static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const
     return 0;
 }
 
-template <int S4C, bool HAS_W>
-static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P0, const State<float>& S, const MfmaArgs& A)
+template <typename Tile, int S4C, bool HAS_W>
+static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P0, const State<typename Tile::R>& S,
+                                 const MfmaArgsT<typename Tile::R>& A)
 {
-    using Pol = MfmaRecorr<S4C, HAS_W>;
+    using Pol = MfmaRecorr<Tile, S4C, HAS_W>;
     DevParams P = P0;
     set_segments(P, Pol::kMaxSegments);
     const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
-    auto kern = iterate_kernel<float, Pol>;
+    auto kern = iterate_kernel<typename Tile::R, Pol>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     if (getenv("HSCMP_DEBUG")) {
         int per_cu = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds);
-        fprintf(stderr, "[hscmp] iterate_kernel<mfma S4=%d w=%d>: dynamic LDS %zu B (control %zu B), occupancy API %d blocks/CU (%s), seg=%d nseg=%d\n",
-                S4C, (int)HAS_W, lds, sizeof(typename Pol::Shared), per_cu, hipGetErrorString(e), P.seg, P.nseg);
+        fprintf(stderr, "[hscmp] iterate_kernel<mfma %s S4=%d w=%d>: dynamic LDS %zu B (control %zu B), occupancy API %d blocks/CU (%s), seg=%d nseg=%d\n",
+                sizeof(typename Tile::R) == 4 ? "f32" : "f64", S4C, (int)HAS_W, lds, sizeof(typename Pol::Shared), per_cu,
+                hipGetErrorString(e), P.seg, P.nseg);
     }
     hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, stream, P, S, A);
     return 0;
 }
 
-inline MfmaArgs mfma_args(const DevParams& P, const State<float>& S, const float* dimg)
+template <typename R> inline MfmaArgsT<R> mfma_args(const DevParams& P, const State<R>& S, const R* dimg)
 {
-    MfmaArgs A;
-    A.dimg = dimg; A.G = mfma_groups(P.K); A.S4 = mfma_chunks(P.W); A.has_w = S.weights != nullptr;
+    using Tile = typename TileOf<R>::type;
+    MfmaArgsT<R> A;
+    A.dimg = dimg; A.G = Tile::groups(P.K); A.S4 = mfma_chunks(P.W); A.has_w = S.weights != nullptr;
     return A;
 }
 
-#define HSCMP_MFMA_DISPATCH(FN)                                                         \
-    do {                                                                                \
-        const bool hw = A.has_w != 0;                                                   \
-        switch (A.S4) {                                                                 \
-        case 8: return hw ? FN<8, true>(stream, P, S, A) : FN<8, false>(stream, P, S, A);   \
-        case 4: return hw ? FN<4, true>(stream, P, S, A) : FN<4, false>(stream, P, S, A);   \
-        case 2: return hw ? FN<2, true>(stream, P, S, A) : FN<2, false>(stream, P, S, A);   \
-        default: return hw ? FN<0, true>(stream, P, S, A) : FN<0, false>(stream, P, S, A);  \
-        }                                                                               \
+#define HSCMP_MFMA_DISPATCH(FN)                                                                       \
+    do {                                                                                              \
+        const bool hw = A.has_w != 0;                                                                 \
+        switch (A.S4) {                                                                               \
+        case 8: return hw ? FN<Tile, 8, true>(stream, P, S, A) : FN<Tile, 8, false>(stream, P, S, A);  \
+        case 4: return hw ? FN<Tile, 4, true>(stream, P, S, A) : FN<Tile, 4, false>(stream, P, S, A);  \
+        case 2: return hw ? FN<Tile, 2, true>(stream, P, S, A) : FN<Tile, 2, false>(stream, P, S, A);  \
+        default: return hw ? FN<Tile, 0, true>(stream, P, S, A) : FN<Tile, 0, false>(stream, P, S, A); \
+        }                                                                                             \
     } while (0)
 
-inline int mfma_launch_corr_init(hipStream_t stream, const DevParams& P, const State<float>& S, const float* dimg)
+template <typename R> inline int mfma_launch_corr_init(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg)
 {
-    const MfmaArgs A = mfma_args(P, S, dimg);
+    using Tile = typename TileOf<R>::type;
+    const MfmaArgsT<R> A = mfma_args<R>(P, S, dimg);
     HSCMP_MFMA_DISPATCH(mfma_launch_corr_init_t);
 }
 
-inline int mfma_launch_iterate(hipStream_t stream, const DevParams& P, const State<float>& S, const float* dimg)
+template <typename R> inline int mfma_launch_iterate(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg)
 {
-    const MfmaArgs A = mfma_args(P, S, dimg);
+    using Tile = typename TileOf<R>::type;
+    const MfmaArgsT<R> A = mfma_args<R>(P, S, dimg);
     HSCMP_MFMA_DISPATCH(mfma_launch_iterate_t);
 }
 

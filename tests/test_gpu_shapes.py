@@ -23,9 +23,9 @@ SHAPES = [
 ]
 
 
-def _inputs(T, K, W, seed, weights):
+def _inputs(T, K, W, seed, weights, dtype=np.float32):
     import hsc_amd.synth as synth
-    D = synth.make_dictionary(K, W, seed=seed)
+    D = synth.make_dictionary(K, W, seed=seed, dtype=dtype)
     x = synth.make_signal(D, T, seed, kind='planted', nb_atoms=max(4, T // 150), noise=0.05, seed=seed).astype(np.float64)
     rs = np.random.RandomState(seed)
     # atoms hanging over both edges
@@ -34,17 +34,20 @@ def _inputs(T, K, W, seed, weights):
         x[s:e] += c * D[k][es:ee]
     w = None
     if weights:
-        w = (0.5 + rs.random_sample(K)).astype(np.float32)
-    return x.astype(np.float32), D, w
+        w = (0.5 + rs.random_sample(K)).astype(dtype)
+    return x.astype(dtype), D, w
 
 
 @pytest.mark.parametrize('idx', range(len(SHAPES)))
 @pytest.mark.parametrize('weights', [False, True])
-def test_mfma_path_vs_oracle(idx, weights):
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_mfma_path_vs_oracle(idx, weights, dtype):
     from hsc_amd.modeling import ConvolutionalMatchingPursuit
     from oracle import hsc_oracle as orc
     T, K, W, kw = SHAPES[idx]
-    x, D, w = _inputs(T, K, W, 100 + idx, weights)
+    if dtype == np.float64 and K * W * 8 > 128 * 1024:
+        pytest.skip('dictionary image larger than the float64 MFMA path holds')
+    x, D, w = _inputs(T, K, W, 100 + idx, weights, dtype)
     kw = dict(kw)
     if w is not None:
         kw['weights'] = w
