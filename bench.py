@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
+PEAK_FP64_MFMA_TFLOPS = 78.6      # AMD MI355X datasheet (v_mfma_f64_16x16x4_f64); used with --dtype f64 only
 
 
 def cpu_baseline(cfg, nproc, per_proc):
@@ -38,10 +39,11 @@ def cpu_baseline(cfg, nproc, per_proc):
     import hsc_amd.synth as synth
     from oracle import numpy_port as port
 
-    D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2)
+    npdt = np.float64 if cfg.get('dtype') == 'f64' else np.float32
+    D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2, dtype=npdt)
     jobs = []
     for p in range(nproc):
-        sig = [synth.make_signal(D, cfg['T'], p * per_proc + i, kind=cfg['kind'], nb_atoms=cfg['L0'], seed=2)
+        sig = [synth.make_signal(D, cfg['T'], p * per_proc + i, kind=cfg['kind'], nb_atoms=cfg['L0'], seed=2, dtype=npdt)
                for i in range(per_proc)]
         jobs.append((D, sig, cfg['L0']))
     t0 = time.perf_counter()
@@ -71,6 +73,7 @@ def main():
     ap.add_argument('--W', type=int, default=64)
     ap.add_argument('--L0', type=int, default=256)
     ap.add_argument('--kind', default='planted', choices=['planted', 'noise'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'], help='arithmetic type of the path (BASELINE config 2 is f32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI) or 'gloo' (rehearsal)")
     ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the CPU baseline (0 = min(8, cores))')
@@ -86,7 +89,7 @@ def main():
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                              % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
-    cfg = dict(B=args.batch, T=args.T, K=args.K, W=args.W, L0=args.L0, kind=args.kind)
+    cfg = dict(B=args.batch, T=args.T, K=args.K, W=args.W, L0=args.L0, kind=args.kind, dtype=args.dtype)
 
     os.environ.setdefault('OMP_NUM_THREADS', '1')
     os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
@@ -115,9 +118,10 @@ def main():
             dist.init_process_group(args.backend)
 
     # ---- synthetic inputs: this rank's shard of the (weakly scaled) batch, resident in HBM
-    D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2)
+    npdt = np.float64 if args.dtype == 'f64' else np.float32
+    D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2, dtype=npdt)
     first = rank * cfg['B']
-    x_host = synth.make_batch(D, cfg['T'], first, cfg['B'], kind=cfg['kind'], nb_atoms=cfg['L0'], seed=2)
+    x_host = synth.make_batch(D, cfg['T'], first, cfg['B'], kind=cfg['kind'], nb_atoms=cfg['L0'], seed=2, dtype=npdt)
     x = torch.from_numpy(x_host).to(dev)
     del x_host
 
@@ -126,7 +130,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
     eng.set_dictionary(D)
     params = _native.make_params(nbNonzeroCoefs=cfg['L0'], nbBlocks=1, minCoefficients=1e-16,
-                                 eps=float(np.finfo(np.float32).eps), maxEvents=2 * cfg['L0'] + 64)
+                                 eps=float(np.finfo(npdt).eps), maxEvents=2 * cfg['L0'] + 64)
 
     def step():
         eng.encode_batch_device(x.data_ptr(), cfg['B'], cfg['T'], params)
@@ -179,13 +183,14 @@ def main():
                 ('iterate (greedy loop re-correlation, modeling.py:1018-1051)', flop_loop, kms[2])]
         dom = max(kern, key=lambda k: k[2])
         achieved = dom[1] / (dom[2] * 1e-3) / 1e12
+        peak = PEAK_FP64_MFMA_TFLOPS if args.dtype == 'f64' else PEAK_FP32_MFMA_TFLOPS
         # HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs, gfx950 correction applied by tools/parse_pmc.py); null if not collected
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
             key = 'corr_init_mfma_kernel' if dom is kern[0] else 'iterate_kernel'
-            if cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma'):
+            if cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma') and args.dtype == 'f32':
                 traffic = pmc[key]['hbm_bytes_per_launch']
         except Exception:
             traffic = None
@@ -196,14 +201,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed_max / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: single-level CSC, %d signals/GPU x len %d, %d-atom x %d-tap dict, '
                                    'L0=%d, nbBlocks=1, %s signals' % (cfg['B'], cfg['T'], cfg['K'], cfg['W'], cfg['L0'], cfg['kind']),
                        'signals_per_gpu': cfg['B'], 'T': cfg['T'], 'K': cfg['K'], 'W': cfg['W'], 'L0': cfg['L0'],
                        'selections_per_step': nsel_total, 'variant': variant,
                        'stop_reasons': {_native.STOP_NAMES[i]: int(n) for i, n in enumerate(stops) if n}},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch (PMC)', 'kernel': dom[0],
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch (PMC)', 'kernel': dom[0],
                          'kernel_ms': float(dom[2]),
                          'all_kernels': [{'kernel': k[0], 'algorithmic_tflop': k[1] / 1e12, 'ms': float(k[2]),
                                           'tflops': (k[1] / (k[2] * 1e-3) / 1e12) if k[2] > 0 else None} for k in kern],

@@ -899,7 +899,8 @@ static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P0, const 
     using Pol = MfmaRecorr<Tile, S4C, HAS_W>;
     DevParams P = P0;
     set_segments(P, Pol::kMaxSegments);
-    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    if (const char* pad = getenv("HSCMP_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: force a lower occupancy
     auto kern = iterate_kernel<typename Tile::R, Pol>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     if (getenv("HSCMP_DEBUG")) {
