@@ -12,8 +12,10 @@
  * by tools/make_golden.py from the real reference); see tests/test_oracle_golden.py.
  *
  * Arithmetic that the reference leaves unpinned and the oracle pins (DESIGN.md "Numerics"):
- *   - correlation: c[t,k] = sum_e xpad[(t-off)*F + e] * D[k, e],  e = w*F + f ascending, as ONE
- *     sequential fma chain starting from +0 (numpy defers to BLAS, whose order is unspecified);
+ *   - correlation: c[t,k] = sum_{f,w} xpad[t-off+w, f] * D[k, w, f] as ONE sequential fma chain
+ *     starting from +0, f outer / w inner -- the contraction index order f*W + w of the reference's
+ *     reshape (modeling.py:181-187).  numpy defers to BLAS, whose order is unspecified; with this
+ *     container's OpenBLAS the pinned chain reproduces the reference bit for bit whenever W*F <= ~256;
  *   - energy sums: 256 strided partial sums of rounded squares, then a fixed halving tree
  *     (numpy uses its pairwise summation) -- see hsco_energy_*.
  */
