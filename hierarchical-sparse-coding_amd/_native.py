@@ -23,7 +23,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
            'hscmp_update_inner_products', 'hscmp_encode_batch',
-           'hscmp_encode_batch_device', 'hscmp_continue', 'hscmp_stop_signal', 'hscmp_fetch_events',
+           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
 
@@ -80,6 +80,7 @@ def load_library():
     lib.hscmp_update_inner_products.argtypes = [vp, vp, vp, ci, ci]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
+    lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
     lib.hscmp_continue.argtypes = [vp, ci]
     lib.hscmp_stop_signal.argtypes = [vp, ci]
     lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
@@ -235,6 +236,14 @@ class Engine(object):
         self._check(self._lib.hscmp_encode_batch_device(self._h, ctypes.c_void_p(x_dev_ptr), int(B), int(T),
                                                         ctypes.byref(params)), 'hscmp_encode_batch_device')
         self._batch = (int(B), int(T), int(params.max_events))
+
+    def encode_batch_from_level(self, prev, first, count, minCoefficients, params):
+        """Hierarchical level chaining on the device (modeling.py:1489): the coefficient slots of signals
+        [first, first+count) of engine `prev` become this engine's dense float64 input."""
+        minc = float('nan') if minCoefficients is None else float(minCoefficients)
+        self._check(self._lib.hscmp_encode_batch_from_level(self._h, prev._h, int(first), int(count), ctypes.c_double(minc),
+                                                            ctypes.byref(params)), 'hscmp_encode_batch_from_level')
+        self._batch = (int(count), prev._batch[1], int(params.max_events))
 
     def continue_rounds(self, max_rounds):
         self._check(self._lib.hscmp_continue(self._h, int(max_rounds)), 'hscmp_continue')

@@ -396,6 +396,36 @@ extern "C" int hscmp_encode_batch_device(hscmp_ctx* ctx, const void* x_dev, int 
     return encode_common(ctx, x_dev, false, B, T, params);
 }
 
+extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, int first, int count, double min_coefficients,
+                                             const hscmp_params* params)
+{
+    if (!ctx || !prev) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_encode_batch_from_level: NULL context");
+    if (ctx->dtype != HSCMP_F64) return fail(ctx, HSCMP_ERR_STATE, "hscmp_encode_batch_from_level: the level dictionary must be float64");
+    if (!prev->have_batch) return fail(ctx, HSCMP_ERR_STATE, "hscmp_encode_batch_from_level: the previous level has no results");
+    if (ctx->device != prev->device) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_encode_batch_from_level: contexts on different GPUs");
+    if (ctx->F != prev->K) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_encode_batch_from_level: F=%d of this level != K=%d of the previous one", ctx->F, prev->K);
+    if (!params || first < 0 || count <= 0 || first + count > prev->B) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_encode_batch_from_level: bad signal range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(prev->stream));           // the previous level's results are final
+    const int T = prev->T;
+    DevParams P;
+    int rc = make_params(ctx, count, T, params, &P);
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, P, true))) return rc;
+    const size_t bytes = (size_t)count * T * ctx->F * sizeof(double);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_x, 0, bytes, ctx->stream));
+    const int has_min = !std::isnan(min_coefficients);
+    hipLaunchKernelGGL((scatter_slots_kernel<double>), dim3(count), dim3(kThreads), 0, ctx->stream, (double*)ctx->d_x, T, ctx->F,
+                       prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
+                       has_min ? min_coefficients : 0.0);
+    ctx->P = P; ctx->last = *params; ctx->B = count; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
+    rc = run_encode<double>(ctx, P, ctx->d_x);
+    if (rc) return rc;
+    ctx->have_batch = true;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
 extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
 {
     if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_continue: ctx is NULL");

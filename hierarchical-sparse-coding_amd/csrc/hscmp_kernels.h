@@ -88,6 +88,23 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
     }
 }
 
+// dense next-level input from the previous level's coefficient slots (modeling.py:1489 `todense()` of the
+// CSC matrix built by :1171-1181): x[b][t][k] = slot_a unless it is zero or below min_coefficients.
+//   grid = count, block = kThreads; x [count][T][F] must be zero filled
+template <typename R>
+__global__ __launch_bounds__(kThreads) void scatter_slots_kernel(R* __restrict__ x, int T, int F, const int* __restrict__ slot_t,
+                                                                 const int* __restrict__ slot_k, const double* __restrict__ slot_a,
+                                                                 const int* __restrict__ stats, int cap, int first, int has_min, double minc)
+{
+    const int b = blockIdx.x, src = first + b;
+    const int n = stats[(int64_t)src * ST_COUNT + ST_SLOTS];
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const double a = slot_a[(int64_t)src * cap + i];
+        if (a == 0.0 || (has_min && !(fabs(a) >= minc))) continue;
+        x[((int64_t)b * T + slot_t[(int64_t)src * cap + i]) * F + slot_k[(int64_t)src * cap + i]] = (R)a;
+    }
+}
+
 // per-position best of a materialised inner-product table ip[T][K] (entry point of _selectBestAtoms)
 template <typename R>
 __global__ __launch_bounds__(kThreads) void table_to_best_kernel(const R* __restrict__ ip, int T, int K, const R* __restrict__ w,

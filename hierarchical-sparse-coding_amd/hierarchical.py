@@ -129,35 +129,99 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         return coefficients, residual
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
-                                 returnDistributed=True):
-        """Batch form (the reference has no batch axis): `sequences` [B,T] or [B,T,F]; every level encodes
-        all B signals in one GPU call.  Returns (list over signals of per-level coefficient lists,
-        residuals [B,T(,F)] float64, per-level kernel timings)."""
+                                 returnDistributed=True, chained=True, memoryBudget=64e9):
+        """Batch form (the reference has no batch axis): `sequences` [B,T] (or [B,T,F]); every level encodes
+        many signals per GPU call.  chained=True keeps the level hand-off on the device
+        (hscmp_encode_batch_from_level): the dense [T, K_prev] float64 input of a level (modeling.py:1489)
+        is scattered from the previous level's coefficient slots in GPU memory, in chunks of signals
+        that fit `memoryBudget` bytes -- at BASELINE config 4 that input is 134 MB per signal and can
+        not travel through the host.  chained=False builds the dense inputs on the host (small cases).
+        Returns (per-signal lists of per-level coefficient matrices, residuals [B,T(,F)] float64,
+        per-level kernel timings)."""
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
             raise NotImplementedError("computeCoefficientsBatch runs the greedy engine only: method='cmp'")
-        B = sequences.shape[0]
-        inputs = np.asarray(sequences)
-        per_level, timings = [], []
-        for level in range(multilevelDict.getNbLevels()):
-            if toleranceSnr is not None and isinstance(toleranceSnr, collections.abc.Iterable):
-                targetSnr = toleranceSnr[level]
-            else:
-                targetSnr = toleranceSnr
+        from . import _native
+        from .modeling import _compute_dtype, _slots_to_csc
+        nbLevels = multilevelDict.getNbLevels()
+        B, T = sequences.shape[0], sequences.shape[1]
+
+        def level_setup(level):
+            targetSnr = toleranceSnr[level] if (toleranceSnr is not None and isinstance(toleranceSnr, collections.abc.Iterable)) else toleranceSnr
             D = multilevelDict.getRawDictionary(level)
             nbSingletons = D.shape[0] - multilevelDict.countsNoSingletons[level]
             weights = np.ones((D.shape[0],), dtype=D.dtype)
-            weights[:nbSingletons] = singletonWeight
-            cmp = ConvolutionalMatchingPursuit(device=self.device)
-            res = cmp.computeCoefficientsBatch(inputs, D, toleranceSnr=targetSnr, nbBlocks=nbBlocks, weights=weights)
-            per_level.append(res.coefficients)
-            timings.append(dict(level=level, variant=res.variant, kernel_ms=[float(v) for v in res.kernel_ms],
-                                selections=int(res.stats[:, 4].sum())))
-            if level + 1 < multilevelDict.getNbLevels():
-                inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
+            weights[:nbSingletons] = singletonWeight                   # :1448-1450
+            return D, weights, targetSnr, float(np.finfo(D.dtype).eps)
+
+        def run_level(eng, encode, count, targetSnr, eps):
+            """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
+            maxEvents = 4096
+            while True:
+                params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
+                encode(params)
+                stats = eng.fetch_stats()
+                if np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
+                    maxEvents *= 4
+                    continue
+                break
+            st, sk, sa = eng.fetch_slots()
+            K = eng.K
+            out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+            tm = dict(variant=eng.last_variant(), kernel_ms=[float(v) for v in eng.last_kernel_ms()],
+                      selections=int(stats[:, _native.STAT_ITERATIONS].sum()))
+            return out, tm
+
+        per_level = [[None] * B for _ in range(nbLevels)]
+        timings = []
+        if not chained:
+            inputs = np.asarray(sequences)
+            for level in range(nbLevels):
+                D, weights, targetSnr, _ = level_setup(level)
+                cmp = ConvolutionalMatchingPursuit(device=self.device)
+                res = cmp.computeCoefficientsBatch(inputs, D, toleranceSnr=targetSnr, nbBlocks=nbBlocks, weights=weights)
+                per_level[level] = res.coefficients
+                timings.append(dict(level=level, variant=res.variant, kernel_ms=[float(v) for v in res.kernel_ms],
+                                    selections=int(res.stats[:, 4].sum())))
+                if level + 1 < nbLevels:
+                    inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
+        else:
+            engines = [_native.Engine(self.device) for _ in range(nbLevels)]
+            try:
+                # level 0: the signals themselves, all B at once
+                D, weights, targetSnr, eps = level_setup(0)
+                dt = _compute_dtype(sequences.dtype, D.dtype)
+                x = np.ascontiguousarray(np.asarray(sequences).reshape((B, T, -1)), dtype=dt)
+                D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt)
+                engines[0].set_dictionary(D3, np.asarray(weights, dtype=dt))
+                per_level[0], tm = run_level(engines[0], lambda p: engines[0].encode_batch(x, p), B, targetSnr, eps)
+                tm['level'] = 0
+                timings.append(tm)
+                setups = [None] + [level_setup(l) for l in range(1, nbLevels)]
+                fmax = 1
+                for l in range(1, nbLevels):
+                    Dl, wl = setups[l][0], setups[l][1]
+                    engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
+                    fmax = max(fmax, Dl.shape[2])
+                    timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, chunks=0))
+                chunk = int(max(1, min(B, memoryBudget // (2.5 * T * fmax * 8 + 64 * T))))
+                for first in range(0, B if nbLevels > 1 else 0, chunk):
+                    count = min(chunk, B - first)
+                    for l in range(1, nbLevels):
+                        _, _, targetSnr, eps = setups[l]
+                        prev, pfirst = (engines[0], first) if l == 1 else (engines[l - 1], 0)
+                        coefs, tm = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
+                                              count, targetSnr, eps)
+                        per_level[l][first:first + count] = coefs
+                        acc = timings[l]
+                        acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['chunks'] += 1
+                        acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
+            finally:
+                for e in engines:
+                    e.close()
         coefficients, residuals = [], []
         for b in range(B):
-            cb = self._postprocessCoefficients([per_level[l][b] for l in range(len(per_level))], multilevelDict, returnDistributed)
+            cb = self._postprocessCoefficients([per_level[l][b] for l in range(nbLevels)], multilevelDict, returnDistributed)
             coefficients.append(cb)
             residuals.append(self._calculateResidual(sequences[b], cb, multilevelDict))
         return coefficients, np.stack(residuals, axis=0), timings

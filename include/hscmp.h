@@ -126,6 +126,15 @@ int hscmp_encode_batch(hscmp_ctx* ctx, const void* x, int B, int T, const hscmp_
  * context's stream. */
 int hscmp_encode_batch_device(hscmp_ctx* ctx, const void* x_dev, int B, int T, const hscmp_params* params);
 
+/* Level chaining of the hierarchical encoder (modeling.py:1489, `input = levelCoefficients.todense()`),
+ * entirely on the device: the accumulated coefficients of signals [first, first+count) of `prev`
+ * (its distinct (t,k) slots, clipped like the CSC epilogue modeling.py:1171-1181 with
+ * min_coefficients; NaN = None) become the dense input [count][T][K_prev] of `ctx`, which is then
+ * encoded like hscmp_encode_batch_device.  ctx must hold a float64 dictionary with F == K_prev; both
+ * contexts live on the same GPU. */
+int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, int first, int count, double min_coefficients,
+                                  const hscmp_params* params);
+
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
  * between rounds.  max_rounds <= 0: until converged. */

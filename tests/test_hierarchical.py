@@ -133,13 +133,14 @@ def test_hierarchical_batch_equals_per_signal():
     xs = np.stack([z['x'], (z['x'][::-1]).copy(), (z['x'] * 0.5 + 0.02 * rs.standard_normal(z['x'].shape)).astype(np.float32)])
     hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
     kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9)
-    coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
-    assert len(timings) == 3 and timings[1]['variant'].startswith('sparse_init+gathered_loop')
-    for b in range(xs.shape[0]):
-        c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
-        for l in range(3):
-            assert (coefs[b][l] != c1[l]).nnz == 0
-        assert np.array_equal(residuals[b], r1)
+    for chained, budget in ((True, 64e9), (True, 2.5e6), (False, 64e9)):     # 2.5 MB: forces 1-2 signals per chunk
+        coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, chained=chained, memoryBudget=budget, **kw)
+        assert len(timings) == 3 and timings[1]['variant'].startswith('sparse_init+gathered_loop')
+        for b in range(xs.shape[0]):
+            c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
+            for l in range(3):
+                assert (coefs[b][l] != c1[l]).nnz == 0
+            assert np.array_equal(residuals[b], r1)
 
 
 def test_events_wire_format_matches_reference():
