@@ -23,7 +23,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
            'hscmp_update_inner_products', 'hscmp_encode_batch',
-           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_stop_signal', 'hscmp_fetch_events',
+           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
 
@@ -82,6 +82,7 @@ def load_library():
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
     lib.hscmp_continue.argtypes = [vp, ci]
+    lib.hscmp_grow_events.argtypes = [vp, ci]
     lib.hscmp_stop_signal.argtypes = [vp, ci]
     lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
     lib.hscmp_fetch_stats.argtypes = [vp, vp]
@@ -247,6 +248,11 @@ class Engine(object):
 
     def continue_rounds(self, max_rounds):
         self._check(self._lib.hscmp_continue(self._h, int(max_rounds)), 'hscmp_continue')
+
+    def grow_events(self, max_events):
+        """Larger event / slot lists, contents kept; signals stopped on capacity run again on continue_rounds()."""
+        self._check(self._lib.hscmp_grow_events(self._h, int(max_events)), 'hscmp_grow_events')
+        self._batch = (self._batch[0], self._batch[1], int(max_events))
 
     def stop_signal(self, b):
         self._check(self._lib.hscmp_stop_signal(self._h, int(b)), 'hscmp_stop_signal')

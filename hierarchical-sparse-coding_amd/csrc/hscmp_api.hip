@@ -32,12 +32,20 @@ struct hscmp_ctx {
     void* d_Dfrag = nullptr;  // MFMA fragment-ordered copy (f32, F == 1)
     void* d_Dt = nullptr;     // [W][F][K] transposed copy for the sparsity-aware kernels (F > 1)
     void* d_scratch = nullptr;
+    int* d_nzptr = nullptr;   // CSR of the dictionary's non-zeros per atom, chain order (sparse level dictionaries)
+    int* d_nzwf = nullptr;
+    void* d_nzval = nullptr;
+    int* d_fptr = nullptr;    // the same non-zeros grouped by feature
+    int* d_fkw = nullptr;
+    void* d_fval = nullptr;
+    unsigned char* d_rowflag = nullptr;  // [B][T] non-zero input rows handed over by the level chaining
+    bool rowflag_valid = false;
     size_t Dfrag_bytes = 0;
     // batch workspace
     int B = 0, T = 0, cap = 0, maxsel = 0;
     bool have_batch = false;
     size_t caps[16] = {0};
-    size_t cap_scratch = 0;
+    size_t cap_scratch = 0, cap_rowflag = 0;
     void* d_x = nullptr;      // staging for host inputs
     void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
@@ -48,6 +56,7 @@ struct hscmp_ctx {
     hscmp_params last{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
 };
 
 static thread_local std::string g_err;
@@ -103,7 +112,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 
 static void free_all(hscmp_ctx* c)
 {
-    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_scratch, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
+    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
                     c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -149,6 +158,12 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     if (ctx->d_w) { (void)hipFree(ctx->d_w); ctx->d_w = nullptr; }
     if (ctx->d_Dfrag) { (void)hipFree(ctx->d_Dfrag); ctx->d_Dfrag = nullptr; ctx->Dfrag_bytes = 0; }
     if (ctx->d_Dt) { (void)hipFree(ctx->d_Dt); ctx->d_Dt = nullptr; }
+    if (ctx->d_nzptr) { (void)hipFree(ctx->d_nzptr); ctx->d_nzptr = nullptr; }
+    if (ctx->d_nzwf) { (void)hipFree(ctx->d_nzwf); ctx->d_nzwf = nullptr; }
+    if (ctx->d_nzval) { (void)hipFree(ctx->d_nzval); ctx->d_nzval = nullptr; }
+    if (ctx->d_fptr) { (void)hipFree(ctx->d_fptr); ctx->d_fptr = nullptr; }
+    if (ctx->d_fkw) { (void)hipFree(ctx->d_fkw); ctx->d_fkw = nullptr; }
+    if (ctx->d_fval) { (void)hipFree(ctx->d_fval); ctx->d_fval = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_D, nD));
     HIP_TRY(ctx, hipMemcpy(ctx->d_D, D, nD, hipMemcpyHostToDevice));
     if (weights) {
@@ -166,6 +181,55 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
                     memcpy(&dt[(((size_t)w * F + f) * K + k) * es], (const char*)D + (((size_t)k * W + w) * F + f) * es, es);
         HIP_TRY(ctx, hipMalloc(&ctx->d_Dt, nD));
         HIP_TRY(ctx, hipMemcpy(ctx->d_Dt, dt.data(), nD, hipMemcpyHostToDevice));
+        // per-atom list of non-zeros in chain order (f outer, w inner), kept when the dictionary is sparse
+        // (level dictionaries built from decompositions + singletons, hsc/dataset.py:137-194, 826-860)
+        if (W <= 32767 && F <= 65535 && !getenv("HSCMP_NO_DICT_LISTS")) {
+            std::vector<int> ptr(K + 1, 0), wf;
+            std::vector<char> val;
+            const size_t limit = (size_t)kDictListMaxPerAtom * K;
+            bool sparse = true;
+            for (int k = 0; k < K && sparse; ++k) {
+                for (int f = 0; f < F && sparse; ++f)
+                    for (int w = 0; w < W; ++w) {
+                        const char* src = (const char*)D + (((size_t)k * W + w) * F + f) * es;
+                        const bool nz = dtype == HSCMP_F32 ? (*(const float*)src != 0.0f) : (*(const double*)src != 0.0);
+                        if (!nz) continue;
+                        if (wf.size() >= limit) { sparse = false; break; }
+                        wf.push_back((w << 16) | f);
+                        val.insert(val.end(), src, src + es);
+                    }
+                ptr[k + 1] = (int)wf.size();
+            }
+            if (sparse) {
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nzptr, (K + 1) * sizeof(int)));
+                HIP_TRY(ctx, hipMemcpy(ctx->d_nzptr, ptr.data(), (K + 1) * sizeof(int), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nzwf, std::max<size_t>(1, wf.size()) * sizeof(int)));
+                HIP_TRY(ctx, hipMemcpy(ctx->d_nzwf, wf.data(), wf.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMalloc(&ctx->d_nzval, std::max<size_t>(es, val.size())));
+                HIP_TRY(ctx, hipMemcpy(ctx->d_nzval, val.data(), val.size(), hipMemcpyHostToDevice));
+                // grouped by feature: counting sort of the per-atom lists
+                if (K <= 65535) {
+                    const size_t nnz = wf.size();
+                    std::vector<int> fp(F + 1, 0), kw(nnz);
+                    std::vector<char> fv(std::max<size_t>(es, nnz * es));
+                    for (size_t e = 0; e < nnz; ++e) fp[(wf[e] & 0xffff) + 1] += 1;
+                    for (int f = 0; f < F; ++f) fp[f + 1] += fp[f];
+                    std::vector<int> cur(fp.begin(), fp.end() - 1);
+                    for (int k = 0; k < K; ++k)
+                        for (int e = ptr[k]; e < ptr[k + 1]; ++e) {
+                            const int o = cur[wf[e] & 0xffff]++;
+                            kw[o] = (int)(((unsigned)k << 16) | (unsigned)(wf[e] >> 16));
+                            memcpy(&fv[(size_t)o * es], &val[(size_t)e * es], es);
+                        }
+                    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_fptr, (F + 1) * sizeof(int)));
+                    HIP_TRY(ctx, hipMemcpy(ctx->d_fptr, fp.data(), (F + 1) * sizeof(int), hipMemcpyHostToDevice));
+                    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_fkw, std::max<size_t>(1, nnz) * sizeof(int)));
+                    HIP_TRY(ctx, hipMemcpy(ctx->d_fkw, kw.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+                    HIP_TRY(ctx, hipMalloc(&ctx->d_fval, fv.size()));
+                    HIP_TRY(ctx, hipMemcpy(ctx->d_fval, fv.data(), fv.size(), hipMemcpyHostToDevice));
+                }
+            }
+        }
     }
     // MFMA operand image of the dictionary (f32 only): built once, reused by every encode
     if (dtype == HSCMP_F32 && mfma_supported<float>(K, W, F)) {
@@ -219,6 +283,13 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
 // every buffer tracks its own capacity in bytes (element size changes with the dictionary dtype)
 struct BufCap { void** p; size_t* cap; size_t bytes; };
 
+// Workgroups per signal of the sparse initial correlation: enough to fill the chip at small batches.
+static int sparse_init_split(int B, int T, int W)
+{
+    const int nblocks = (T + 2 * W - 2) / (2 * W - 1);
+    return std::max(1, std::min(nblocks, (2048 + B - 1) / B));
+}
+
 static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
 {
     const size_t es = esize(ctx->dtype);
@@ -240,7 +311,8 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
         {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
         {(void**)&ctx->d_edge, &ctx->caps[15], B * 2 * sizeof(unsigned long long)},
-        {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)(2 * P.W - 1) * P.K * es : 0},
+        {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)sparse_init_split(P.B, P.T, P.W) * (2 * P.W - 1) * P.K * es : 0},
+        {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, ctx->F > 1 ? B * T : 0},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -288,10 +360,14 @@ static bool use_sparse_init(const hscmp_ctx* ctx, int T)
     return use_sparse_loop(ctx) && ctx->F > 1 && T <= 262144;
 }
 
-template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx)
+template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)
 {
     SparseArgs<R> A;
     A.Dt = (const R*)ctx->d_Dt; A.scratch = (R*)ctx->d_scratch;
+    A.rowflag = (T <= kRowBitsMaxT && !getenv("HSCMP_NO_ROWBITS")) ? ctx->d_rowflag : nullptr;
+    A.rowflag_filled = ctx->rowflag_valid ? 1 : 0;
+    A.nzptr = ctx->d_nzptr; A.nzwf = ctx->d_nzwf; A.nzval = (const R*)ctx->d_nzval;
+    A.fptr = getenv("HSCMP_NO_PAIRING") ? nullptr : ctx->d_fptr; A.fkw = ctx->d_fkw; A.fval = (const R*)ctx->d_fval;
     return A;
 }
 
@@ -300,20 +376,21 @@ template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const Dev
     State<R> S = make_state<R>(ctx);
     DevParams P = P0;
     set_segments(P, SparseRecorr<R>::kMaxSegments);
-    const size_t lds = ((sizeof(typename SparseRecorr<R>::Shared) + 15) / 16) * 16 + sizeof(SparseLds<R>);
+    const SparseArgs<R> A = sparse_args<R>(ctx, P.T);
+    const size_t lds = ((sizeof(typename SparseRecorr<R>::Shared) + 15) / 16) * 16 + SparseRecorr<R>::extra_lds_bytes(P, A);
     auto kern = iterate_kernel<R, SparseRecorr<R>>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
 }
 
 template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const DevParams& P)
 {
     State<R> S = make_state<R>(ctx);
-    const size_t lds = ((sizeof(SparseLds<R>) + 15) / 16) * 16 + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
+    const size_t lds = sparse_lds_bytes<R>() + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
     auto kern = corr_init_sparse_kernel<R>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx));
+    hipLaunchKernelGGL(kern, dim3(P.B, sparse_init_split(P.B, P.T, P.W)), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx, P.T));
     return HSCMP_OK;
 }
 
@@ -357,8 +434,8 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     else if (!mfi) launch_iterate<R>(ctx, P);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
-    ctx->timed = true;
-    ctx->variant = std::string(mf ? "mfma" : spi ? "sparse" : "generic") + "_init+" + (mfi ? "mfma" : spl ? "gathered" : "generic") +
+    ctx->timed = true; ctx->timed_loop_only = false;
+    ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
                    "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
     return HSCMP_OK;
 }
@@ -414,12 +491,15 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     if ((rc = ensure_workspace(ctx, P, true))) return rc;
     const size_t bytes = (size_t)count * T * ctx->F * sizeof(double);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_x, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rowflag, 0, (size_t)count * T, ctx->stream));
     const int has_min = !std::isnan(min_coefficients);
     hipLaunchKernelGGL((scatter_slots_kernel<double>), dim3(count), dim3(kThreads), 0, ctx->stream, (double*)ctx->d_x, T, ctx->F,
                        prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
-                       has_min ? min_coefficients : 0.0);
+                       has_min ? min_coefficients : 0.0, ctx->d_rowflag);
     ctx->P = P; ctx->last = *params; ctx->B = count; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
+    ctx->rowflag_valid = true;                  // the sparse initial correlation skips its scan of the dense input
     rc = run_encode<double>(ctx, P, ctx->d_x);
+    ctx->rowflag_valid = false;
     if (rc) return rc;
     ctx->have_batch = true;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -434,6 +514,8 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
     DevParams P = ctx->P;
     P.max_rounds = max_rounds;
     bool mfi = false;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));       // hscmp_last_kernel_ms: [2] = this launch, [0] = [1] = 0
+    ctx->timed_loop_only = true;
     if (use_mfma(ctx, P.T)) {
         if (ctx->dtype == HSCMP_F32) {
             State<float> S = make_state<float>(ctx);
@@ -448,7 +530,36 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         if (rc) return rc;
     } else if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_grow_events(hscmp_ctx* ctx, int new_max_events)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_grow_events: ctx is NULL");
+    if (!ctx->have_batch) return fail(ctx, HSCMP_ERR_STATE, "hscmp_grow_events: no batch encoded");
+    if (new_max_events <= ctx->cap) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_grow_events: %d is not above the current capacity %d", new_max_events, ctx->cap);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t es = esize(ctx->dtype), B = (size_t)ctx->B, oc = (size_t)ctx->cap, nc = (size_t)new_max_events;
+    struct Row { void** p; size_t* cap; size_t elem; };
+    Row rows[] = {{(void**)&ctx->d_ev_t, &ctx->caps[4], 4}, {(void**)&ctx->d_ev_k, &ctx->caps[5], 4}, {(void**)&ctx->d_ev_c, &ctx->caps[6], es},
+                  {(void**)&ctx->d_slot_t, &ctx->caps[7], 4}, {(void**)&ctx->d_slot_k, &ctx->caps[8], 4}, {(void**)&ctx->d_slot_a, &ctx->caps[9], 8}};
+    for (const Row& r : rows) {
+        void* fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, B * nc * r.elem);
+        if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", B * nc * r.elem, hipGetErrorString(e));
+        HIP_TRY(ctx, hipMemcpy2D(fresh, nc * r.elem, *r.p, oc * r.elem, oc * r.elem, B, hipMemcpyDeviceToDevice));
+        (void)hipFree(*r.p);
+        *r.p = fresh; *r.cap = B * nc * r.elem;
+    }
+    std::vector<int> stats(B * ST_COUNT);
+    HIP_TRY(ctx, hipMemcpy(stats.data(), ctx->d_stats, stats.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b)
+        if (stats[b * ST_COUNT + ST_STOP] == STOP_CAPACITY) stats[b * ST_COUNT + ST_STOP] = STOP_RUNNING;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_stats, stats.data(), stats.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx->cap = new_max_events; ctx->P.cap = new_max_events; ctx->last.max_events = new_max_events;
     return HSCMP_OK;
 }
 
@@ -556,8 +667,8 @@ extern "C" int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4)
     if (!ctx->timed) return fail(ctx, HSCMP_ERR_STATE, "hscmp_last_kernel_ms: nothing timed yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
-    for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(&out4[i], ctx->ev[i], ctx->ev[i + 1]));
-    out4[3] = 0.f;
+    out4[0] = out4[1] = out4[3] = 0.f;
+    for (int i = ctx->timed_loop_only ? 2 : 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(&out4[i], ctx->ev[i], ctx->ev[i + 1]));
     return HSCMP_OK;
 }
 

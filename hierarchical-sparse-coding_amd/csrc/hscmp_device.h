@@ -18,6 +18,18 @@ namespace hscmp {
 __device__ unsigned long long g_stamps[16];      // per-phase cycle sums of workgroup 0
 __device__ unsigned long long g_blk[3 * 4096];   // per workgroup: start, end (100 MHz wall clock), XCC/HW id
 #endif
+#ifdef HSCMP_DBG_STAMPS
+// diagnostic build only: per-phase cycle sums of workgroup 0 (thread 0), read back by
+// tools/read_stamps.py / tools/hsc_stamps.py through hscmp_debug_stamps(); never compiled into the product library
+#define HSCMP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_stamps[i] += now_ - stamp_last_; stamp_last_ = now_; } } while (0)
+#define HSCMP_STAMP_BEGIN() unsigned long long stamp_last_ = clock64()
+#define HSCMP_COUNT(i) (g_stamps[i] += 1)
+#else
+#define HSCMP_STAMP(i) do {} while (0)
+#define HSCMP_STAMP_BEGIN() do {} while (0)
+#define HSCMP_COUNT(i) ((void)0)
+#endif
+
 
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
 constexpr int kWaves = kThreads / 64;

@@ -94,14 +94,17 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
 template <typename R>
 __global__ __launch_bounds__(kThreads) void scatter_slots_kernel(R* __restrict__ x, int T, int F, const int* __restrict__ slot_t,
                                                                  const int* __restrict__ slot_k, const double* __restrict__ slot_a,
-                                                                 const int* __restrict__ stats, int cap, int first, int has_min, double minc)
+                                                                 const int* __restrict__ stats, int cap, int first, int has_min, double minc,
+                                                                 unsigned char* __restrict__ rowflag)
 {
     const int b = blockIdx.x, src = first + b;
     const int n = stats[(int64_t)src * ST_COUNT + ST_SLOTS];
     for (int i = threadIdx.x; i < n; i += kThreads) {
         const double a = slot_a[(int64_t)src * cap + i];
         if (a == 0.0 || (has_min && !(fabs(a) >= minc))) continue;
-        x[((int64_t)b * T + slot_t[(int64_t)src * cap + i]) * F + slot_k[(int64_t)src * cap + i]] = (R)a;
+        const int t = slot_t[(int64_t)src * cap + i];
+        x[((int64_t)b * T + t) * F + slot_k[(int64_t)src * cap + i]] = (R)a;
+        rowflag[(int64_t)b * T + t] = 1;                   // non-zero input row (rowflag must be zero filled)
     }
 }
 
@@ -403,8 +406,10 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
 
+    HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         int nsel;
+        if constexpr (!Recorr::kFused) HSCMP_STAMP(7);
         // =========================== select (modeling.py:899-982) ===========================
         int p_sel = 0, k_sel = 0;
         R c_sel = (R)0;
@@ -528,6 +533,14 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
             return;
         }
+        if constexpr (!Recorr::kFused) HSCMP_STAMP(0);
+        // A round whose atoms do not all fit the event list is not started: the state then is exactly that
+        // of a round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
+        if (sh.nev + nsel > P.cap) {                   // uniform (LDS values after a barrier)
+            __syncthreads();
+            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
+            break;
+        }
         // =========================== apply the selected atoms (:1101-1142) ===========================
         bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
         for (int ai = 0; ai < nsel; ++ai) {
@@ -562,6 +575,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
             __syncthreads();
             if (sh.skip) break;
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(1);
 
             // ---- :1117, :996-1016 residual subtract with local energy before / after
             int s, e, es;
@@ -594,9 +608,11 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
             }
 
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(2);
             // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
             Recorr::run(P, S, G, sh, A, plds, p);
             __syncthreads();
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(3);
 
             // ---- refresh the maxima of the touched segments
             {
@@ -616,6 +632,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 }
             }
             __syncthreads();
+            if constexpr (!Recorr::kFused) { HSCMP_STAMP(4); if (blockIdx.x == 0 && tid == 0) HSCMP_COUNT(14); }
             if (sh.converged) break;
         }
 

@@ -316,16 +316,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifdef HSCMP_DBG_STAMPS
-// diagnostic build only: per-phase cycle sums of workgroup 0 (thread 0), read back by
-// tools/time_variants.py through hscmp_debug_stamps(); never compiled into the product library
-#define HSCMP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_stamps[i] += now_ - stamp_last_; stamp_last_ = now_; } } while (0)
-#define HSCMP_STAMP_BEGIN() unsigned long long stamp_last_ = clock64()
-#else
-#define HSCMP_STAMP(i) do {} while (0)
-#define HSCMP_STAMP_BEGIN() do {} while (0)
-#endif
-
 constexpr int kBloomWords = 256;          // 8192-bit Bloom filter over the selected (t,k) pairs
 __device__ __forceinline__ unsigned bloom_hash(int t, int k)
 {

@@ -10,6 +10,16 @@
 // result); the (f outer, w inner) order of the pinned chain is the (feature, row) sort order.
 // Windows that are not sparse (more than kNzMax entries) fall back to the dense chain.
 //
+// Level dictionaries built from decompositions (hsc/dataset.py:137-194, a few lower-level events per
+// atom plus the unit "singleton" atoms of :826-860) are themselves almost all zero.  For those only
+// the non-zero products are formed: every gathered input non-zero (f, j) is paired with the
+// dictionary non-zeros (k, w) of feature f, the pairs are sorted by (output, chain order) and one
+// thread per output runs its chain.  All other outputs are +0.
+//
+// A per-signal row-occupancy bitmap (which residual rows may hold a non-zero) keeps the gather from
+// touching the zero rows: it starts from the non-zero input rows and grows by the span of every
+// subtracted atom.
+//
 // Used for both the initial correlation (zero padded, modeling.py:1077) -- only rows within reach
 // of a non-zero input row can be non-zero -- and the local re-correlation after each atom
 // (reflect padded, modeling.py:1018-1051).
@@ -19,11 +29,26 @@
 
 namespace hscmp {
 
-constexpr int kNzMax = 1024;            // gathered non-zeros per row block (LDS list)
+constexpr int kNzMax = 256;             // gathered non-zeros per row block (LDS list)
+constexpr int kRecMax = 256;            // (input non-zero, dictionary non-zero) pairs per row block (<= 1024: 10-bit index)
+constexpr int kWinRowsMax = 256;        // occupied rows of one window (LDS list)
+constexpr int kDictListMaxPerAtom = 32; // a dictionary with at most this many non-zeros per atom (average) gets per-atom lists
+constexpr int kRowBitsMaxT = 262144;    // longest signal with a row-occupancy bitmap in LDS (32 KB)
 
 template <typename R> struct SparseArgs {
     const R* Dt;        // dictionary transposed to [W][F][K] (coalesced over atoms)
     R* scratch;         // [B][(2W-1)*K] per-workgroup table of the rows being recomputed
+    unsigned char* rowflag;   // [B][T] 1 = the residual row may hold a non-zero (nullptr: no bitmap, T too long)
+    int rowflag_filled; // the flags of the input were written by the caller (level chaining): no scan of the input
+    // Non-zeros of a sparse dictionary, per atom in chain order (f outer, w inner); nullptr when the
+    // dictionary is not sparse enough (then the window's non-zeros meet the dense dictionary).
+    const int* nzptr;   // [K+1]
+    const int* nzwf;    // [nnz] (w << 16) | f
+    const R* nzval;     // [nnz]
+    // the same non-zeros grouped by feature (for the sparse-input x sparse-dictionary pairing)
+    const int* fptr;    // [F+1]
+    const int* fkw;     // [nnz] (k << 16) | w
+    const R* fval;      // [nnz]
 };
 
 template <typename R> struct SparseLds {
@@ -32,8 +57,19 @@ template <typename R> struct SparseLds {
     R sval[kNzMax];     // sorted copies
     int skey[kNzMax];
     int count;
-    int wtot[kWaves];
+    // occupied rows of the window: local row, global (reflected) row
+    int rowj[kWinRowsMax], rowg[kWinRowsMax];
+    int nwinrows;
+    // pairing of a sparse window with a sparse dictionary: one record per non-zero product
+    unsigned long long rkey[kRecMax];   // row << 48 | k << 32 | f << 16 | w : output first, then chain order
+    R rx[kRecMax], rd[kRecMax];         // the two factors
+    int perm[kRecMax];                  // sorted position -> record
+    unsigned okey[kRecMax];             // per sorted position: row << 16 | k if it starts an output's chain, else ~0
+    R out[kRecMax];                     // chain result, at the chain's first sorted position
+    int nrec;
 };
+
+template <typename R> __host__ __device__ constexpr size_t sparse_lds_bytes() { return ((sizeof(SparseLds<R>) + 15) / 16) * 16; }
 
 // Dense chain for output rows [row0, row0+nrows) (global positions), all atoms: the generic
 // fallback.  reflect: np.pad 'reflect' w.r.t. the slice [sidx, sidx+nslice) (modeling.py:1046);
@@ -62,56 +98,173 @@ __device__ __forceinline__ void dense_rows_to_table(const DevParams& P, const R*
     }
 }
 
+// Non-zeros of the residual rows [g0, g0+nwin) (reflected / zero padded) -> L.val / L.key, in any
+// order.  rowbits (LDS, may be nullptr): only rows whose bit is set are read.  Returns the number
+// of non-zeros found (> kNzMax: the list overflowed and is unusable).  Contains barriers.
+template <typename R>
+__device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G, SparseLds<R>& L, const unsigned* rowbits,
+                                             int g0, int nwin, bool reflect, int sidx, int nslice)
+{
+    const int T = P.T, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { L.count = 0; L.nrec = 0; L.nwinrows = 0; }
+    __syncthreads();
+    // rows that exist (zero padding) and may hold a non-zero
+    for (int j = tid; j < nwin; j += kThreads) {
+        int g = g0 + j;
+        bool ok = true;
+        if (reflect) g = reflect_index(g, sidx, nslice);
+        else ok = g >= 0 && g < T;
+        if (ok && rowbits) ok = ((rowbits[g >> 5] >> (g & 31)) & 1u) != 0;
+        if (ok) {
+            const int o = atomicAdd(&L.nwinrows, 1);
+            if (o < kWinRowsMax) { L.rowj[o] = j; L.rowg[o] = g; }
+        }
+    }
+    __syncthreads();
+    const int nr = L.nwinrows;
+    if (nr > kWinRowsMax) return kNzMax + 1;
+    // (row, 64-feature chunk) items round-robin over the waves, four loads in flight per lane
+    const int nchunks = (F + 63) >> 6;
+    const int items = nr * nchunks;
+    for (int it0 = wv; it0 < items; it0 += kWaves * 4) {
+        R v[4];
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u * kWaves;
+            v[u] = (R)0; key[u] = 0;
+            if (it < items) {
+                const int q = it / nchunks, f = ((it - q * nchunks) << 6) + lane;
+                if (f < F) { v[u] = G.r[(int64_t)L.rowg[q] * F + f]; key[u] = (f << 16) | L.rowj[q]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != (R)0) {
+                const int o = atomicAdd(&L.count, 1);
+                if (o < kNzMax) { L.val[o] = v[u]; L.key[o] = key[u]; }
+            }
+    }
+    __syncthreads();
+    return L.count;
+}
+
 // Rows [row0, row0+nrows) x all atoms -> per-position best (best_c, best_k), sparsity aware.
 //   nrows <= 2W-1 (table capacity).  All threads of the workgroup call it (contains barriers).
 template <typename R>
 __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& S, const Sig<R>& G, const SparseArgs<R>& A,
-                                            SparseLds<R>& L, int row0, int nrows, bool reflect, int sidx, int nslice)
+                                            SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
+                                            int sidx, int nslice)
 {
     const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     R* tab = A.scratch + (int64_t)blockIdx.x * (2 * W - 1) * K;
     const int nwin = nrows + W - 1;                 // residual rows the block can see
     const int g0 = row0 - P.off;                    // global row of local row 0
 
-    // ---- 1. gather the non-zeros of the window, row-major (coalesced), order-preserving
-    if (tid == 0) L.count = 0;
-    __syncthreads();
-    const int total = nwin * F;
-    int running = 0;
-    bool overflow = false;
-    for (int base = 0; base < total; base += kThreads) {
-        const int e = base + tid;
-        R v = (R)0;
-        int j = 0, f = 0;
-        if (e < total) {
-            j = e / F; f = e - j * F;
-            int g = g0 + j;
-            if (reflect) { g = reflect_index(g, sidx, nslice); v = G.r[(int64_t)g * F + f]; }
-            else if (g >= 0 && g < T) v = G.r[(int64_t)g * F + f];
-        }
-        const int flag = (v != (R)0) ? 1 : 0;
-        const unsigned long long mask = __ballot(flag);
-        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) L.wtot[wv] = __popcll(mask);
-        __syncthreads();
-        int before = 0, tot = 0;
-#pragma unroll
-        for (int q = 0; q < kWaves; ++q) { const int c = L.wtot[q]; if (q < wv) before += c; tot += c; }
-        if (flag) {
-            const int o = running + before + prefix;
-            if (o < kNzMax) { L.val[o] = v; L.key[o] = (f << 16) | j; }
-        }
-        running += tot;
-        if (running > kNzMax) { overflow = true; break; }       // uniform
-    }
-    __syncthreads();
+    // ---- 1. the non-zeros of the window (any order)
+    const int n = gather_window(P, G, L, rowbits, g0, nwin, reflect, sidx, nslice);
 
-    if (overflow) {
+    if (A.fptr && n <= kNzMax) {
+        // ---- sparse window x sparse dictionary: only the non-zero products are formed.
+        //  a. pair every input non-zero (f, j) with the dictionary non-zeros (k, w) of feature f: output row j - w
+        for (int i = tid; i < n; i += kThreads) {
+            const int key = L.key[i], f = key >> 16, j = key & 0xffff;
+            const R v = L.val[i];
+            const int e1 = A.fptr[f + 1];
+            for (int e = A.fptr[f]; e < e1; ++e) {
+                const int kw = A.fkw[e], w = kw & 0xffff, row = j - w;
+                if (row < 0 || row >= nrows) continue;
+                const int t = row0 + row;
+                if (t < 0 || t >= T) continue;
+                const int o = atomicAdd(&L.nrec, 1);
+                if (o < kRecMax) {
+                    L.rkey[o] = ((unsigned long long)row << 48) | ((unsigned long long)((unsigned)kw >> 16) << 32) |
+                                ((unsigned long long)f << 16) | (unsigned)w;
+                    L.rx[o] = v; L.rd[o] = A.fval[e];
+                }
+            }
+        }
+        __syncthreads();
+        const int m = L.nrec;
+        if (m <= kRecMax) {
+            //  b. sort by (output, chain order): rank sort, the keys are distinct
+            for (int i = tid; i < m; i += kThreads) {
+                const unsigned long long key = L.rkey[i];
+                int rank = 0;
+                for (int q = 0; q < m; ++q) rank += (L.rkey[q] < key) ? 1 : 0;
+                L.perm[rank] = i;
+            }
+            __syncthreads();
+            //  c. one chain per output, run by the thread of its first record (f outer, w inner from +0)
+            for (int sp = tid; sp < m; sp += kThreads) {
+                const unsigned ok = (unsigned)(L.rkey[L.perm[sp]] >> 32);
+                unsigned mark = ~0u;
+                if (sp == 0 || (unsigned)(L.rkey[L.perm[sp - 1]] >> 32) != ok) {
+                    R acc = (R)0;
+                    for (int q = sp; q < m; ++q) {
+                        const int rec = L.perm[q];
+                        if ((unsigned)(L.rkey[rec] >> 32) != ok) break;
+                        acc = rfma(L.rx[rec], L.rd[rec], acc);
+                    }
+                    L.out[sp] = acc;
+                    mark = ok;
+                }
+                L.okey[sp] = mark;
+            }
+            __syncthreads();
+            //  d. per-row best over atoms: the listed outputs against the zeros of all the others
+            //     (a zero score never beats k = 0, the first of the ties)
+            for (int row = wv; row < nrows; row += kWaves) {
+                const int t = row0 + row;
+                if (t < 0 || t >= T) continue;                       // overlapReplace clipping (utils.py:133-161)
+                Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+                int at0 = -1;
+                for (int sp = lane; sp < m; sp += 64) {
+                    const unsigned ok = L.okey[sp];
+                    if (ok == ~0u || (int)(ok >> 16) != row) continue;
+                    const int k = (int)(ok & 0xffffu);
+                    if (k == 0) at0 = sp;
+                    Cand<R> o; o.s = score_of(L.out[sp], k, S.weights); o.i = (k << 10) | sp;
+                    if (better(o, best)) best = o;
+                }
+                best = wave_argmax(best);
+                const unsigned long long has0 = __ballot(at0 >= 0);
+                R c; int k;
+                if (best.i != INT_MAX && best.s > (R)0) { k = best.i >> 10; c = L.out[best.i & 1023]; }
+                else {
+                    k = 0; c = (R)0;
+                    if (has0) { const int sp0 = __shfl(at0, __ffsll((long long)has0) - 1); c = L.out[sp0]; }
+                }
+                if (lane == 0) { G.bc[t] = c; G.bk[t] = k; }
+            }
+            __syncthreads();
+            return;
+        }
+    }
+
+    if (A.nzptr) {
+        // sparse dictionary, window or pair list too long: each output walks its atom's non-zeros (already in chain order)
+        for (int o = tid; o < nrows * K; o += kThreads) {
+            const int row = o / K, k = o - row * K;
+            const int t = row0 + row;
+            R acc = (R)0;
+            if (t >= 0 && t < T) {
+                const int e1 = A.nzptr[k + 1];
+                for (int e = A.nzptr[k]; e < e1; ++e) {
+                    const int wf = A.nzwf[e];
+                    int g = g0 + row + (wf >> 16);
+                    R xv;
+                    if (reflect) { g = reflect_index(g, sidx, nslice); xv = G.r[(int64_t)g * F + (wf & 0xffff)]; }
+                    else xv = (g >= 0 && g < T) ? G.r[(int64_t)g * F + (wf & 0xffff)] : (R)0;
+                    acc = rfma(xv, A.nzval[e], acc);
+                }
+            }
+            tab[o] = acc;
+        }
+    } else if (n > kNzMax) {
         dense_rows_to_table(P, G.r, S.D, row0, nrows, reflect, sidx, nslice, tab);
     } else {
         // ---- 2. sort by (feature, row): the pinned chain order f outer / w inner (rank sort)
-        const int n = running;
         for (int i = tid; i < n; i += kThreads) {
             const int key = L.key[i];
             int rank = 0;
@@ -151,14 +304,41 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
 // policy of iterate_kernel: local re-correlation of the 2W-1 touched rows, reflect padded
 // ------------------------------------------------------------------------------------------------
 template <typename R> struct SparseRecorr {
-    static constexpr int kMaxSegments = kMaxSeg;
+    // LDS per workgroup is kept near 40 KB (4 workgroups per CU): the loop is latency bound, not compute bound
+    static constexpr int kMaxSegments = 512;
     static constexpr bool kFused = false;
     static constexpr bool kScoreOnly = false;
-    using Shared = IterSharedT<R, kMaxSeg>;
+    using Shared = IterSharedT<R, kMaxSegments, false>;
     using Args = SparseArgs<R>;
-    static size_t extra_lds_bytes(const DevParams&) { return sizeof(SparseLds<R>); }
-    static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
-    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __host__ __device__ bool has_bits(const DevParams& P, const Args& A) { return A.rowflag != nullptr && P.T <= kRowBitsMaxT; }
+    static size_t extra_lds_bytes(const DevParams& P, const Args& A)
+    {
+        return sparse_lds_bytes<R>() + (has_bits(P, A) ? (size_t)((P.T + 31) / 32) * sizeof(unsigned) : 0);
+    }
+    static __device__ __forceinline__ unsigned* bits_of(char* lds) { return reinterpret_cast<unsigned*>(lds + sparse_lds_bytes<R>()); }
+    // the row-occupancy bitmap of this signal: flags written by the initial correlation (or an earlier launch)
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>&, const Args& A, char* lds)
+    {
+        if (!has_bits(P, A)) return;
+        unsigned* bits = bits_of(lds);
+        const unsigned char* rf = A.rowflag + (int64_t)blockIdx.x * P.T;
+        const int nwords = (P.T + 31) / 32;
+        for (int i = threadIdx.x; i < nwords; i += kThreads) {
+            unsigned word = 0;
+            const int t0 = i * 32, n = min(32, P.T - t0);
+            for (int q = 0; q < n; ++q) word |= rf[t0 + q] ? (1u << q) : 0u;
+            bits[i] = word;
+        }
+        __syncthreads();
+    }
+    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>&, const Args& A, char* lds)
+    {
+        if (!has_bits(P, A)) return;                        // (the caller's barrier made all bits visible)
+        const unsigned* bits = bits_of(lds);
+        unsigned char* rf = A.rowflag + (int64_t)blockIdx.x * P.T;
+        for (int t = threadIdx.x; t < P.T; t += kThreads)
+            if ((bits[t >> 5] >> (t & 31)) & 1u) rf[t] = 1;  // kept for resumed launches (hscmp_continue)
+    }
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
     template <typename SH>
@@ -167,46 +347,70 @@ template <typename R> struct SparseRecorr {
     {
         SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(lds);
         const int T = P.T, W = P.W;
+        unsigned* bits = has_bits(P, A) ? bits_of(lds) : nullptr;
+        if (bits) {
+            // the atom just subtracted made its span possibly non-zero (utils.py:76-131)
+            int s, e, es;
+            centered_span(T, W, p, s, e, es);
+            for (int t = s + (int)threadIdx.x; t < e; t += kThreads) atomicOr(&bits[t >> 5], 1u << (t & 31));
+        }                                                  // (ordered by the first barrier of gather_window)
         const int tstart = p - P.off - (W - 1);            // :1028-1033
         const int tend = p + W / 2 + (W - 1);              // :1038
         const int sidx = tstart < 0 ? 0 : tstart;          // :1034
         const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
-        sparse_rows(P, S, G, A, L, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1);
+        sparse_rows(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1);
     }
 };
 
 // ------------------------------------------------------------------------------------------------
 // initial correlation of a sparse multi-feature input (modeling.py:1077): only rows whose window
 // contains a non-zero input row can be non-zero; everything else is (c = 0, k = 0).
-//   grid = B, block = kThreads;  dynamic LDS = SparseLds<R> + T bits of row flags
+//   grid = (B, nsplit): workgroup (b, y) owns a contiguous range of (2W-1)-row blocks of signal b;
+//   block = kThreads;  dynamic LDS = SparseLds<R> + T bits of row flags.
+//   A.scratch needs B * nsplit tables.
 // ------------------------------------------------------------------------------------------------
 template <typename R>
-__global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P, State<R> S, SparseArgs<R> A)
+__global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P, State<R> S, SparseArgs<R> A0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(smem);
-    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + ((sizeof(SparseLds<R>) + 15) / 16) * 16);   // [ceil(T/32)]
+    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + sparse_lds_bytes<R>());   // [ceil(T/32)]
     const int b = blockIdx.x, tid = threadIdx.x, T = P.T, W = P.W, F = P.F;
+    SparseArgs<R> A = A0;
+    A.scratch = A0.scratch + ((int64_t)blockIdx.y * gridDim.x) * (2 * W - 1) * P.K;   // sparse_rows adds blockIdx.x tables
     Sig<R> G{};
     G.r = S.residual + (int64_t)b * T * F;
     G.bc = S.best_c + (int64_t)b * T;
     G.bk = S.best_k + (int64_t)b * T;
-    const int nwords = (T + 31) / 32;
-    for (int i = tid; i < nwords; i += kThreads) rowbits[i] = 0u;
-    for (int t = tid; t < T; t += kThreads) { G.bc[t] = (R)0; G.bk[t] = 0; }
-    __syncthreads();
-    // input rows with a non-zero sample
-    for (int64_t e = tid; e < (int64_t)T * F; e += kThreads)
-        if (G.r[e] != (R)0) atomicOr(&rowbits[(int)(e / F) >> 5], 1u << ((int)(e / F) & 31));
-    __syncthreads();
-    // walk the output rows in blocks of up to 2W-1; a block is computed iff some input row in its reach is set
+    // this workgroup's output rows [r_lo, r_hi) and the input rows they can see [in_lo, in_hi)
     const int blk = 2 * W - 1;
-    for (int row0 = 0; row0 < T; row0 += blk) {
+    const int nblocks = (T + blk - 1) / blk;
+    const int per = (nblocks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_lo = min(T, (int)blockIdx.y * per * blk), r_hi = min(T, ((int)blockIdx.y + 1) * per * blk);
+    if (r_lo >= r_hi) return;
+    const int in_lo = max(0, r_lo - P.off), in_hi = min(T, r_hi - P.off + W - 1);
+    for (int i = (in_lo >> 5) + tid; i <= ((in_hi - 1) >> 5); i += kThreads) rowbits[i] = 0u;
+    for (int t = r_lo + tid; t < r_hi; t += kThreads) { G.bc[t] = (R)0; G.bk[t] = 0; }
+    __syncthreads();
+    // input rows with a non-zero sample: handed over by the level chaining, or found by a scan
+    unsigned char* rf = A.rowflag ? A.rowflag + (int64_t)b * T : nullptr;
+    if (rf && A.rowflag_filled) {
+        for (int t = in_lo + tid; t < in_hi; t += kThreads) if (rf[t]) atomicOr(&rowbits[t >> 5], 1u << (t & 31));
+    } else {
+        const int64_t e0 = (int64_t)in_lo * F, e1 = (int64_t)in_hi * F;
+        for (int64_t e = e0 + tid; e < e1; e += kThreads)
+            if (G.r[e] != (R)0) atomicOr(&rowbits[(int)(e / F) >> 5], 1u << ((int)(e / F) & 31));
+    }
+    __syncthreads();
+    if (rf && !A.rowflag_filled)                         // publish the flags of the owned rows for the greedy loop
+        for (int t = r_lo + tid; t < r_hi; t += kThreads) rf[t] = (unsigned char)((rowbits[t >> 5] >> (t & 31)) & 1u);
+    // walk the output rows in blocks of up to 2W-1; a block is computed iff some input row in its reach is set
+    for (int row0 = r_lo; row0 < r_hi; row0 += blk) {
         const int nrows = min(blk, T - row0);
         const int lo = max(0, row0 - P.off), hi = min(T - 1, row0 + nrows - 1 - P.off + W - 1);
         int any = 0;
         for (int t = lo + tid; t <= hi; t += kThreads) any |= (rowbits[t >> 5] >> (t & 31)) & 1u;
-        if (__syncthreads_or(any)) sparse_rows(P, S, G, A, L, row0, nrows, false, 0, 0);
+        if (__syncthreads_or(any)) sparse_rows(P, S, G, A, L, rowbits, row0, nrows, false, 0, 0);
     }
 }
 

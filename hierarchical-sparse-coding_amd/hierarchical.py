@@ -154,21 +154,23 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             weights[:nbSingletons] = singletonWeight                   # :1448-1450
             return D, weights, targetSnr, float(np.finfo(D.dtype).eps)
 
-        def run_level(eng, encode, count, targetSnr, eps):
+        def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
-            maxEvents = 4096
+            params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
+            encode(params)
+            kernel_ms = [float(v) for v in eng.last_kernel_ms()]
             while True:
-                params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
-                encode(params)
                 stats = eng.fetch_stats()
-                if np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
-                    maxEvents *= 4
-                    continue
-                break
+                if not np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
+                    break
+                maxEvents *= 4                       # enlarge the event lists and resume (exact, see hscmp_grow_events)
+                eng.grow_events(maxEvents)
+                eng.continue_rounds(0)
+                kernel_ms[2] += float(eng.last_kernel_ms()[2])
             st, sk, sa = eng.fetch_slots()
             K = eng.K
             out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
-            tm = dict(variant=eng.last_variant(), kernel_ms=[float(v) for v in eng.last_kernel_ms()],
+            tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
                       selections=int(stats[:, _native.STAT_ITERATIONS].sum()))
             return out, tm
 
@@ -210,8 +212,10 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     for l in range(1, nbLevels):
                         _, _, targetSnr, eps = setups[l]
                         prev, pfirst = (engines[0], first) if l == 1 else (engines[l - 1], 0)
+                        # every input non-zero is explained at least once (by its singleton): size the lists for that
+                        nin = int(prev.fetch_stats()[pfirst:pfirst + count, _native.STAT_SLOTS].max())
                         coefs, tm = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
-                                              count, targetSnr, eps)
+                                              count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64))
                         per_level[l][first:first + count] = coefs
                         acc = timings[l]
                         acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['chunks'] += 1

@@ -74,9 +74,35 @@ def reconstructSignal(coefficients, D):
         dense = np.asarray(coefficients)
         rows, cols = np.nonzero(dense)
         data = dense[rows, cols]
-    for t, k, c in zip(rows, cols, data):
-        if c != 0.0:
+    keep = data != 0.0
+    rows, cols, data = rows[keep], cols[keep], data[keep]
+    if np.result_type(data.dtype, D3.dtype) != signal.dtype:
+        # mixed precision: keep numpy's scalar-by-scalar casting of the reference loop
+        for t, k, c in zip(rows, cols, data):
             overlapAdd(signal, c * D3[k], int(t), copy=False)
+    else:
+        # the same sums in the same order (np.add.at is unbuffered: per sample, the events add up in
+        # event order exactly as the reference's sequential overlap-add), a block of events at a time
+        T, (W, Fd) = signal.shape[0], D3.shape[1:]
+        flat = signal.reshape(-1)
+        taps = np.arange(W, dtype=np.int64)
+        feats = np.arange(Fd, dtype=np.int64)
+        one_pass = signal.dtype == np.float64 and len(data) * W * Fd <= (1 << 25)
+        step = len(data) if one_pass else max(1, (1 << 22) // (W * Fd))
+        for i0 in range(0, len(data), max(1, step)):
+            r = np.asarray(rows[i0:i0 + step], dtype=np.int64)
+            pos = r[:, np.newaxis] - (W - 1) // 2 + taps[np.newaxis, :]                  # utils.py:84-99
+            elems = (data[i0:i0 + step, np.newaxis, np.newaxis] * D3[cols[i0:i0 + step]]).reshape(-1, Fd)   # c * D[k]
+            pos = pos.reshape(-1)
+            if r.size and (int(r.min()) < (W - 1) // 2 or int(r.max()) + W // 2 >= T):
+                inside = np.flatnonzero((pos >= 0) & (pos < T))                          # clipped at the edges
+                pos, elems = pos[inside], elems[inside]
+            idx = pos if Fd == 1 else (pos[:, np.newaxis] * Fd + feats[np.newaxis, :]).reshape(-1)
+            if one_pass:
+                # bincount accumulates its float64 weights one by one in input order, from 0.0
+                flat[:] = np.bincount(idx, weights=elems.reshape(-1), minlength=flat.shape[0])
+            else:
+                np.add.at(flat, idx, elems.reshape(-1))
     if squeezeOutput:
         signal = np.squeeze(signal, axis=1)
     return signal
@@ -215,17 +241,22 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         if maxEvents is None:
             maxEvents = 2 * int(nbNonzeroCoefs) + 64 if nbNonzeroCoefs is not None else 4096
         per_round = stopCondition is not None
+        params = _native.make_params(nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
+                                     minCoefficients, eps, maxEvents, 1 if per_round else 0)
+        eng.encode_batch(x, params)
+        kernel_ms = list(eng.last_kernel_ms())
         while True:
-            params = _native.make_params(nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
-                                         minCoefficients, eps, maxEvents, 1 if per_round else 0)
-            eng.encode_batch(x, params)
             if per_round:
                 self._run_with_callback(eng, sequences, D, K, T, minCoefficients, stopCondition)
             stats = eng.fetch_stats()
-            if np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
-                maxEvents *= 4          # event list was too short for this stop rule: start over, larger
-                continue
-            break
+            if not np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
+                break
+            # the event list was too short for this stop rule: enlarge it and resume where the loop stopped
+            # (a round is only started when all its atoms fit, so the trace equals an uninterrupted run)
+            maxEvents *= 4
+            eng.grow_events(maxEvents)
+            eng.continue_rounds(1 if per_round else 0)
+            kernel_ms[2] += eng.last_kernel_ms()[2]
 
         ev_t, ev_k, ev_c = eng.fetch_events()
         st, sk, sa = eng.fetch_slots()
@@ -240,7 +271,7 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
             residuals = np.squeeze(residuals, axis=2)                      # modeling.py:1183-1184
         if residuals.dtype != sequences.dtype and np.issubdtype(sequences.dtype, np.floating):
             residuals = residuals.astype(sequences.dtype)
-        res = BatchResult(coefficients, residuals, events, stats, energies, eng.last_variant(), eng.last_kernel_ms())
+        res = BatchResult(coefficients, residuals, events, stats, energies, eng.last_variant(), kernel_ms)
         self.lastResult = res
         if self.verbose:
             for b in range(B):

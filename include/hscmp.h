@@ -140,6 +140,13 @@ int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, int first, in
  * between rounds.  max_rounds <= 0: until converged. */
 int hscmp_continue(hscmp_ctx* ctx, int max_rounds);
 
+/* Enlarge the per-signal event / slot lists to new_max_events (> the current max_events), keeping
+ * their contents, and put the signals that stopped with HSCMP_STOP_CAPACITY back to HSCMP_RUNNING.
+ * A round is never started unless all its atoms fit the lists, so hscmp_continue() afterwards
+ * reproduces an uninterrupted run bit for bit (the reference's lists are unbounded Python objects,
+ * modeling.py:1101-1114). */
+int hscmp_grow_events(hscmp_ctx* ctx, int new_max_events);
+
 /* Mark signal b as converged by the host-side stopCondition (modeling.py:1155-1158). */
 int hscmp_stop_signal(hscmp_ctx* ctx, int b);
 

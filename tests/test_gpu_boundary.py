@@ -40,15 +40,40 @@ def test_stop_condition_callback_equals_l0_rule():
     assert cmp1.lastResult.stop_reasons() == ['callback'] and cmp2.lastResult.stop_reasons() == ['nnz']
 
 
-def test_event_capacity_regrowth():
+@pytest.mark.parametrize('force_generic', [False, True])
+@pytest.mark.parametrize('kw', [dict(nbNonzeroCoefs=20), dict(toleranceSnr=12.0, nbBlocks=4), dict(toleranceSnr=10.0, nbBlocks='auto')])
+def test_event_capacity_regrowth(kw, force_generic, monkeypatch):
+    """Event lists that are far too short are enlarged in place (hscmp_grow_events) and the loop resumed:
+    same trace, residual and statistics as a run that never hit the limit -- rounds of several atoms
+    (blocked selection) are never split."""
     from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    if force_generic:
+        monkeypatch.setenv('HSCMP_FORCE_GENERIC', '1')
     x, D = _setup()
     a = ConvolutionalMatchingPursuit()
-    a.computeCoefficientsBatch(x[np.newaxis], D, nbNonzeroCoefs=20, maxEvents=4)     # far too small: must regrow
+    a.computeCoefficientsBatch(x[np.newaxis], D, maxEvents=3, **kw)     # far too small: must grow (3 -> 12 -> 48 ...)
     b = ConvolutionalMatchingPursuit()
-    b.computeCoefficientsBatch(x[np.newaxis], D, nbNonzeroCoefs=20)
+    b.computeCoefficientsBatch(x[np.newaxis], D, maxEvents=8192, **kw)
+    assert len(b.lastResult.events[0][0]) > 12
     assert all(np.array_equal(u, v) for u, v in zip(a.lastResult.events[0], b.lastResult.events[0]))
-    assert len(a.lastResult.events[0][0]) >= 20
+    assert np.array_equal(a.lastResult.residuals, b.lastResult.residuals)
+    assert np.array_equal(a.lastResult.stats[:, :5], b.lastResult.stats[:, :5])
+    assert (a.lastResult.coefficients[0] != b.lastResult.coefficients[0]).nnz == 0
+
+
+def test_event_capacity_regrowth_with_callback():
+    """Growth in stopCondition mode (one launch per round): the callback is not evaluated twice on the same state."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    x, D = _setup()
+    seen = []
+
+    def stop(sequence, residual, coefficients):
+        seen.append(coefficients.nnz)
+        return coefficients.nnz >= 9
+
+    a = ConvolutionalMatchingPursuit()
+    a.computeCoefficientsBatch(x[np.newaxis], D, stopCondition=stop, maxEvents=2)
+    assert seen == list(range(1, 10))
 
 
 def test_resumed_launches_equal_one_launch():

@@ -135,7 +135,7 @@ def test_hierarchical_batch_equals_per_signal():
     kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9)
     for chained, budget in ((True, 64e9), (True, 2.5e6), (False, 64e9)):     # 2.5 MB: forces 1-2 signals per chunk
         coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, chained=chained, memoryBudget=budget, **kw)
-        assert len(timings) == 3 and timings[1]['variant'].startswith('sparse_init+gathered_loop')
+        assert len(timings) == 3 and timings[1]['variant'].startswith('dictlist_init+dictlist_loop')
         for b in range(xs.shape[0]):
             c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
             for l in range(3):

@@ -1,0 +1,46 @@
+"""Diagnostic: per-phase cycle shares of the generic (non-fused) atom body on a level-1 shaped input
+(libhscmp built with -DHSCMP_DBG_STAMPS, path in argv[1])."""
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hsc_amd.synth as synth
+from hsc_amd import _native
+_native.LIB_PATH = os.path.abspath(sys.argv[1])
+from hsc_amd.dataset import MultilevelDictionary
+from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+
+B = int(os.environ.get('B', '8')); T = int(os.environ.get('T', '65536'))
+K0, W0, K1, W1 = 256, 64, 128, 16
+rs = np.random.RandomState(11)
+D0 = synth.make_dictionary(K0, W0, seed=4)
+D1 = np.zeros((K1, W1, K0), dtype=np.float32)
+for k in range(K1):
+    for _ in range(3):
+        D1[k, rs.randint(0, W1), rs.randint(0, K0)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+    D1[k] /= np.sqrt(np.sum(D1[k] ** 2))
+mld = MultilevelDictionary.fromRawDictionaries([D0, D1], [W0, W0 + W1 - 1]).withSingletonBases()
+rep1 = mld.getMultiscaleDictionaries()[1]
+xs = []
+for b in range(B):
+    x = 0.01 * rs.standard_normal(T)
+    for _ in range(T // 128):
+        i = rs.randint(K0, rep1.shape[0]); t = rs.randint(64, T - 64); c = rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0])
+        s, e, es, ee = synth.centered_span(T, rep1.shape[1], t)
+        x[s:e] += c * rep1[i][es:ee]
+    xs.append(x.astype(np.float32))
+xs = np.stack(xs)
+lib = _native.load_library()
+out = (ctypes.c_ulonglong * 16)()
+hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+lib.hscmp_debug_stamps(out, 1)
+coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, toleranceSnr=[30.0, 40.0], nbBlocks=10, singletonWeight=0.95)
+lib.hscmp_debug_stamps(out, 1)
+v = np.array(list(out), dtype=np.float64)
+n = max(v[14], 1)
+for tm in timings:
+    print('level %d: %-28s init %.2f ms  loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
+print('NOTE: indices 0-7 also receive the fused level-0 loop of workgroup 0 (small next to level 1)')
+names = ['select (per round)', 'bookkeeping', 'residual update', 're-correlation', 'segments + stop', '-', '-', 'slow stop rules (per round)']
+print('workgroup 0: %d atoms' % n)
+for i, nm in enumerate(names):
+    print('  %-28s %9.0f cycles/atom' % (nm, v[i] / n))
+print('  total %.0f cycles/atom' % (v[:8].sum() / n))
