@@ -208,6 +208,36 @@ __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G
     }
 }
 
+// arg-max of the per-position best over the block [lo,hi) by one wave, through the segment maxima:
+// segments that lie entirely inside the block are read from LDS, only the two ragged ends are
+// scanned.  Same result as wave_range_argmax (maximum score, lowest position among equals).
+template <bool SO, typename R, typename SH>
+__device__ __forceinline__ Cand<R> wave_block_argmax(const DevParams& P, const Sig<R>& G, const R* w, const SH& sh,
+                                                     int lo, int hi, int lane)
+{
+    const int sgA = (lo + P.seg - 1) >> P.seg_shift;                        // first segment entirely inside
+    const int sgB = (hi >= P.T) ? P.nseg - 1 : (hi >> P.seg_shift) - 1;     // last one (the last segment of the signal may be short)
+    if (sgA > sgB) return wave_range_argmax<SO>(G, w, lo, hi, lane);
+    Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+    const int headEnd = sgA << P.seg_shift, tailBegin = min(hi, (sgB + 1) << P.seg_shift);
+    // per lane the candidates come in ascending position, so '>' keeps the first of equals
+    for (int t = lo + lane; t < headEnd; t += 64) {
+        R sc;
+        if constexpr (SO) sc = G.bc[t]; else sc = score_of(G.bc[t], G.bk[t], w);
+        if (sc > best.s) { best.s = sc; best.i = t; }
+    }
+    for (int sg = sgA + lane; sg <= sgB; sg += 64) {
+        const R sc = sh.seg_score[sg];
+        if (sc > best.s) { best.s = sc; best.i = sh.seg_t[sg]; }
+    }
+    for (int t = tailBegin + lane; t < hi; t += 64) {
+        R sc;
+        if constexpr (SO) sc = G.bc[t]; else sc = score_of(G.bc[t], G.bk[t], w);
+        if (sc > best.s) { best.s = sc; best.i = t; }
+    }
+    return wave_argmax(best);
+}
+
 template <typename R, typename SH>
 __device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& G, SH& sh, int sg, int lane)
 {
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 const int lo = w0 < 0 ? 0 : w0;
                 const int hi = min(T, w0 + P.bs);
                 Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
-                if (lo < hi) win = wave_range_argmax<Recorr::kScoreOnly>(G, wts, lo, hi, lane);
+                if (lo < hi) win = wave_block_argmax<Recorr::kScoreOnly>(P, G, wts, sh, lo, hi, lane);
                 bool valid = (lo < hi) && win.i != INT_MAX;                      // :940-942 range test
                 if (valid && win.s == (R)0 && w0 < 0) valid = false;             // arg-max on a leading padded row
                 int wk = 0;

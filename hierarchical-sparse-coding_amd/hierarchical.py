@@ -128,6 +128,18 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         residual = self._calculateResidual(sequence, coefficients, multilevelDict)
         return coefficients, residual
 
+    def _level_engines(self, nbLevels):
+        from . import _native
+        engines = self.__dict__.setdefault('_engines', [])
+        while len(engines) < nbLevels:
+            engines.append(_native.Engine(self.device))
+        return engines[:nbLevels]
+
+    def close(self):
+        """Release the per-level GPU engines (and their workspaces) of computeCoefficientsBatch."""
+        for e in self.__dict__.pop('_engines', []):
+            e.close()
+
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
                                  returnDistributed=True, chained=True, memoryBudget=64e9):
         """Batch form (the reference has no batch axis): `sequences` [B,T] (or [B,T,F]); every level encodes
@@ -188,8 +200,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 if level + 1 < nbLevels:
                     inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
         else:
-            engines = [_native.Engine(self.device) for _ in range(nbLevels)]
-            try:
+            engines = self._level_engines(nbLevels)      # kept across calls: their workspaces are tens of GB
+            if True:
                 # level 0: the signals themselves, all B at once
                 D, weights, targetSnr, eps = level_setup(0)
                 dt = _compute_dtype(sequences.dtype, D.dtype)
@@ -220,9 +232,6 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                         acc = timings[l]
                         acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['chunks'] += 1
                         acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
-            finally:
-                for e in engines:
-                    e.close()
         coefficients, residuals = [], []
         for b in range(B):
             cb = self._postprocessCoefficients([per_level[l][b] for l in range(nbLevels)], multilevelDict, returnDistributed)
