@@ -35,6 +35,7 @@ struct hscmp_ctx {
     int* d_nzptr = nullptr;   // CSR of the dictionary's non-zeros per atom, chain order (sparse level dictionaries)
     int* d_nzwf = nullptr;
     void* d_nzval = nullptr;
+    int dict_nnz = 0;
     int* d_fptr = nullptr;    // the same non-zeros grouped by feature
     int* d_fkw = nullptr;
     void* d_fval = nullptr;
@@ -210,6 +211,7 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
                 // grouped by feature: counting sort of the per-atom lists
                 if (K <= 65535) {
                     const size_t nnz = wf.size();
+                    ctx->dict_nnz = (int)nnz;
                     std::vector<int> fp(F + 1, 0), kw(nnz);
                     std::vector<char> fv(std::max<size_t>(es, nnz * es));
                     for (size_t e = 0; e < nnz; ++e) fp[(wf[e] & 0xffff) + 1] += 1;
@@ -368,6 +370,7 @@ template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)
     A.rowflag_filled = ctx->rowflag_valid ? 1 : 0;
     A.nzptr = ctx->d_nzptr; A.nzwf = ctx->d_nzwf; A.nzval = (const R*)ctx->d_nzval;
     A.fptr = getenv("HSCMP_NO_PAIRING") ? nullptr : ctx->d_fptr; A.fkw = ctx->d_fkw; A.fval = (const R*)ctx->d_fval;
+    A.nnz = ctx->dict_nnz; A.wts = (const R*)ctx->d_w;
     return A;
 }
 
@@ -387,10 +390,11 @@ template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const Dev
 template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const DevParams& P)
 {
     State<R> S = make_state<R>(ctx);
-    const size_t lds = sparse_lds_bytes<R>() + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
+    const SparseArgs<R> A = sparse_args<R>(ctx, P.T);
+    const size_t lds = sparse_lds_bytes<R>() + staged_dict_bytes(P, A) + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
     auto kern = corr_init_sparse_kernel<R>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(P.B, sparse_init_split(P.B, P.T, P.W)), dim3(kThreads), lds, ctx->stream, P, S, sparse_args<R>(ctx, P.T));
+    hipLaunchKernelGGL(kern, dim3(P.B, sparse_init_split(P.B, P.T, P.W)), dim3(kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
 }
 

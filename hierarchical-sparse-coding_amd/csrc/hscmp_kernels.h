@@ -153,7 +153,16 @@ __global__ __launch_bounds__(kThreads) void update_rows_kernel(DevParams P, cons
 // ------------------------------------------------------------------------------------------------
 // shared state of the greedy loop
 // ------------------------------------------------------------------------------------------------
+constexpr int kBloomWords = 256;          // 8192-bit Bloom filter over the selected (t,k) pairs
+__device__ __forceinline__ unsigned bloom_hash(int t, int k)
+{
+    unsigned h = (unsigned)t * 2654435761u + (unsigned)k * 40503u;
+    h ^= h >> 15;
+    return h & (kBloomWords * 32 - 1);
+}
+
 template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> struct IterSharedT {
+    unsigned bloom[WITH_CK ? kBloomWords : 1];    // step-by-step atom body: (t,k) pairs that own a slot (fused policies keep their own)
     R seg_score[MAXSEG];
     int seg_t[MAXSEG];
     R seg_c[WITH_CK ? MAXSEG : 1];            // coefficient / atom of the segment maximum (not kept by
@@ -287,7 +296,14 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
     if (len > 0) {
         const int n = len * P.F;
         const R* v = G.r + (int64_t)s * P.F;
-        for (int i = threadIdx.x; i < n; i += kThreads) { const R sq = v[i] * v[i]; p = p + sq; }
+        constexpr int kU = 8;                      // loads of a batch issued together
+        for (int i0 = threadIdx.x; i0 < n; i0 += kThreads * kU) {
+            R x[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { const int i = i0 + u * kThreads; x[u] = i < n ? v[i] : (R)0; }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { if (i0 + u * kThreads < n) { const R sq = x[u] * x[u]; p = p + sq; } }
+        }
     }
     pinned_tree2(p, q, sh.red);
     return p;
@@ -307,6 +323,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*) {}
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
+    static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -408,7 +425,6 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     G.ev_t = S.ev_t + (int64_t)b * P.cap; G.ev_k = S.ev_k + (int64_t)b * P.cap; G.ev_c = S.ev_c + (int64_t)b * P.cap;
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
-    const R* __restrict__ wts = S.weights;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
         g_blk[3 * b + 0] = wall_clock64();
@@ -419,6 +435,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     }
 #endif
     Recorr::prologue(P, S, A, plds);
+    const R* wts = Recorr::weights(P, S, A, plds);        // atom weights (a policy may keep a copy in LDS)
 
     // ---- prologue: segment maxima of the per-position best (and of |residual|)
     for (int sg = wv; sg < P.nseg; sg += kWaves) scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
@@ -428,6 +445,16 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
         sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
+    }
+    if constexpr (!Recorr::kFused) {
+        // Bloom filter over the (t,k) pairs that already own a coefficient slot (rebuilt on every launch)
+        for (int i = tid; i < kBloomWords; i += kThreads) sh.bloom[i] = 0u;
+        __syncthreads();
+        const int ns = stats[ST_SLOTS];
+        for (int i = tid; i < ns; i += kThreads) {
+            const unsigned h = bloom_hash(G.slot_t[i], G.slot_k[i]);
+            atomicOr(&sh.bloom[h >> 5], 1u << (h & 31));
+        }
     }
     __syncthreads();
 
@@ -566,7 +593,11 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         if constexpr (!Recorr::kFused) HSCMP_STAMP(0);
         // A round whose atoms do not all fit the event list is not started: the state then is exactly that
         // of a round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
-        if (sh.nev + nsel > P.cap) {                   // uniform (LDS values after a barrier)
+        const bool lists_full = sh.nev + nsel > P.cap;  // uniform (LDS values after a barrier)
+        // every thread has read the event count before thread 0 advances it (the step-by-step body may reach
+        // its bookkeeping without passing another barrier; the fused bodies pass several first)
+        if constexpr (!Recorr::kFused) __syncthreads();
+        if (lists_full) {
             __syncthreads();
             if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
             break;
@@ -585,25 +616,34 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
 
             // ---- :1106-1114 duplicate / nnz bookkeeping, coefficient accumulation, event append
-            if (tid == 0) sh.found = -1;
-            __syncthreads();
-            const int nslots = sh.nslots;
-            for (int i = tid; i < nslots; i += kThreads)
-                if (G.slot_t[i] == p && G.slot_k[i] == k) sh.found = i;          // at most one match
-            __syncthreads();
+            // the slot list is searched only when the Bloom filter says the pair may own a slot already
+            const unsigned hb = bloom_hash(p, k);
+            const bool maybe_dup = ((sh.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;     // uniform (LDS, ordered by the barriers below)
+            if (maybe_dup) {
+                if (tid == 0) sh.found = -1;
+                __syncthreads();
+                const int nslots = sh.nslots;
+                for (int i = tid; i < nslots; i += kThreads)
+                    if (G.slot_t[i] == p && G.slot_k[i] == k) sh.found = i;          // at most one match
+                __syncthreads();
+            }
+            bool new_slot = false;                   // thread 0 only
             if (tid == 0) {
                 if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
                 else {
-                    int si = sh.found;
+                    int si = maybe_dup ? sh.found : -1;
                     if (si >= 0 && fabs(G.slot_a[si]) > 0.0) sh.ndup += 1;
                     else if (rabs(c) > (R)0) sh.nnz += 1;
-                    if (si < 0) { si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; G.slot_a[si] = 0.0; }
+                    if (si < 0) { si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; G.slot_a[si] = 0.0; new_slot = true; }
                     G.slot_a[si] += (double)c;
                     const int e = sh.nev++;
                     G.ev_t[e] = p; G.ev_k[e] = k; G.ev_c[e] = c;
                 }
             }
             __syncthreads();
+            // the filter is updated only now: every thread has read this atom's bit (maybe_dup) before the barrier
+            // above, and the next read comes after the barriers of the residual update
+            if (new_slot) sh.bloom[hb >> 5] |= 1u << (hb & 31);
             if (sh.skip) break;
             if constexpr (!Recorr::kFused) HSCMP_STAMP(1);
 
@@ -616,15 +656,29 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 const R nc = -c;
                 const R* dk = S.D + ((int64_t)k * W + es) * F;
                 R* rv = G.r + (int64_t)s * F;
-                for (int i = tid; i < n; i += kThreads) {
-                    const R v = rv[i];
-                    const R sq = v * v;
-                    pb = pb + sq;
-                    const R prod = nc * dk[i];       // -c*D[k] rounded, then += (utils.py:120,129)
-                    const R vn = v + prod;
-                    rv[i] = vn;
-                    const R sq2 = vn * vn;
-                    pa = pa + sq2;
+                // (the loads of a batch are issued together: one memory round trip per 8 elements of a thread)
+                constexpr int kU = 8;
+                for (int i0 = tid; i0 < n; i0 += kThreads * kU) {
+                    R v[kU], d[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int i = i0 + u * kThreads;
+                        v[u] = (R)0; d[u] = (R)0;
+                        if (i < n) { v[u] = rv[i]; d[u] = dk[i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int i = i0 + u * kThreads;
+                        if (i < n) {
+                            const R sq = v[u] * v[u];
+                            pb = pb + sq;
+                            const R prod = nc * d[u];        // -c*D[k] rounded, then += (utils.py:120,129)
+                            const R vn = v[u] + prod;
+                            rv[i] = vn;
+                            const R sq2 = vn * vn;
+                            pa = pa + sq2;
+                        }
+                    }
                 }
             }
             pinned_tree2(pb, pa, sh.red);

@@ -316,14 +316,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int kBloomWords = 256;          // 8192-bit Bloom filter over the selected (t,k) pairs
-__device__ __forceinline__ unsigned bloom_hash(int t, int k)
-{
-    unsigned h = (unsigned)t * 2654435761u + (unsigned)k * 40503u;
-    h ^= h >> 15;
-    return h & (kBloomWords * 32 - 1);
-}
-
 __device__ __forceinline__ int dimg_index(int k, int w, int S4)
 {
     // float index of D[k][w] inside Dimg[g][s4][lane][q]  (see mfma_build_dict_image)
@@ -548,6 +540,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int kBook = 192;           // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
     using R = typename Tile::R;
     static constexpr int TP = Tile::TP;
+    static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const MfmaArgsT<R>&, char*) { return S.weights; }
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
 

@@ -49,7 +49,43 @@ template <typename R> struct SparseArgs {
     const int* fptr;    // [F+1]
     const int* fkw;     // [nnz] (k << 16) | w
     const R* fval;      // [nnz]
+    int nnz;            // non-zeros of the dictionary (length of the lists)
+    const R* wts;       // atom weights (State::weights, or their LDS copy)
 };
+
+constexpr int kDictLdsBytes = 12288;    // by-feature lists + weights are copied to LDS when they fit this
+
+// LDS bytes of the staged by-feature lists + weights (0: they stay in global memory)
+template <typename R> __host__ __device__ inline size_t staged_dict_bytes(const DevParams& P, const SparseArgs<R>& A)
+{
+    if (!A.fptr) return 0;
+    const size_t b = (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8 + ((size_t)A.nnz + (A.wts ? (size_t)P.K : 0)) * sizeof(R);
+    return b <= (size_t)kDictLdsBytes ? (b + 15) / 16 * 16 : 0;
+}
+
+// Arguments whose lists / weights point at their LDS copies at `base` (unchanged when not staged).
+template <typename R>
+__device__ __forceinline__ SparseArgs<R> dict_view(const DevParams& P, const SparseArgs<R>& A, char* base)
+{
+    SparseArgs<R> B = A;
+    if (staged_dict_bytes(P, A) == 0) return B;
+    int* fptr = reinterpret_cast<int*>(base);
+    R* fval = reinterpret_cast<R*>(base + (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8);
+    B.fptr = fptr; B.fkw = fptr + (P.F + 1); B.fval = fval;
+    if (A.wts) B.wts = fval + A.nnz;
+    return B;
+}
+
+// Copy the lists to LDS at `base` (all threads; the caller synchronises).
+template <typename R>
+__device__ __forceinline__ void stage_dict(const DevParams& P, const SparseArgs<R>& A, char* base)
+{
+    if (staged_dict_bytes(P, A) == 0) return;
+    const SparseArgs<R> B = dict_view(P, A, base);
+    for (int i = threadIdx.x; i <= P.F; i += kThreads) const_cast<int*>(B.fptr)[i] = A.fptr[i];
+    for (int i = threadIdx.x; i < A.nnz; i += kThreads) { const_cast<int*>(B.fkw)[i] = A.fkw[i]; const_cast<R*>(B.fval)[i] = A.fval[i]; }
+    if (A.wts) for (int i = threadIdx.x; i < P.K; i += kThreads) const_cast<R*>(B.wts)[i] = A.wts[i];
+}
 
 template <typename R> struct SparseLds {
     R val[kNzMax];
@@ -224,7 +260,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     if (ok == ~0u || (int)(ok >> 16) != row) continue;
                     const int k = (int)(ok & 0xffffu);
                     if (k == 0) at0 = sp;
-                    Cand<R> o; o.s = score_of(L.out[sp], k, S.weights); o.i = (k << 10) | sp;
+                    Cand<R> o; o.s = score_of(L.out[sp], k, A.wts); o.i = (k << 10) | sp;
                     if (better(o, best)) best = o;
                 }
                 best = wave_argmax(best);
@@ -291,7 +327,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
         if (t < 0 || t >= T) continue;                           // overlapReplace clipping (utils.py:133-161)
         Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
         for (int k = lane; k < K; k += 64) {
-            const R sc = score_of(tab[row * K + k], k, S.weights);
+            const R sc = score_of(tab[row * K + k], k, A.wts);
             if (sc > best.s) { best.s = sc; best.i = k; }
         }
         best = wave_argmax(best);
@@ -311,16 +347,23 @@ template <typename R> struct SparseRecorr {
     using Shared = IterSharedT<R, kMaxSegments, false>;
     using Args = SparseArgs<R>;
     static __host__ __device__ bool has_bits(const DevParams& P, const Args& A) { return A.rowflag != nullptr && P.T <= kRowBitsMaxT; }
+    // policy LDS: SparseLds | staged dictionary lists + weights (when small) | row bitmap (when T allows)
+    static __host__ __device__ size_t bits_offset(const DevParams& P, const Args& A) { return sparse_lds_bytes<R>() + staged_dict_bytes(P, A); }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A)
     {
-        return sparse_lds_bytes<R>() + (has_bits(P, A) ? (size_t)((P.T + 31) / 32) * sizeof(unsigned) : 0);
+        return bits_offset(P, A) + (has_bits(P, A) ? (size_t)((P.T + 31) / 32) * sizeof(unsigned) : 0);
     }
-    static __device__ __forceinline__ unsigned* bits_of(char* lds) { return reinterpret_cast<unsigned*>(lds + sparse_lds_bytes<R>()); }
+    static __device__ __forceinline__ unsigned* bits_of(const DevParams& P, const Args& A, char* lds) { return reinterpret_cast<unsigned*>(lds + bits_offset(P, A)); }
+    static __device__ __forceinline__ const R* weights(const DevParams& P, const State<R>&, const Args& A, char* lds)
+    {
+        return dict_view(P, A, lds + sparse_lds_bytes<R>()).wts;
+    }
     // the row-occupancy bitmap of this signal: flags written by the initial correlation (or an earlier launch)
     static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>&, const Args& A, char* lds)
     {
-        if (!has_bits(P, A)) return;
-        unsigned* bits = bits_of(lds);
+        stage_dict(P, A, lds + sparse_lds_bytes<R>());
+        if (!has_bits(P, A)) { __syncthreads(); return; }
+        unsigned* bits = bits_of(P, A, lds);
         const unsigned char* rf = A.rowflag + (int64_t)blockIdx.x * P.T;
         const int nwords = (P.T + 31) / 32;
         for (int i = threadIdx.x; i < nwords; i += kThreads) {
@@ -334,7 +377,7 @@ template <typename R> struct SparseRecorr {
     static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>&, const Args& A, char* lds)
     {
         if (!has_bits(P, A)) return;                        // (the caller's barrier made all bits visible)
-        const unsigned* bits = bits_of(lds);
+        const unsigned* bits = bits_of(P, A, lds);
         unsigned char* rf = A.rowflag + (int64_t)blockIdx.x * P.T;
         for (int t = threadIdx.x; t < P.T; t += kThreads)
             if ((bits[t >> 5] >> (t & 31)) & 1u) rf[t] = 1;  // kept for resumed launches (hscmp_continue)
@@ -342,12 +385,13 @@ template <typename R> struct SparseRecorr {
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
     template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A,
+    static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
                                                char* lds, int p)
     {
         SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(lds);
         const int T = P.T, W = P.W;
-        unsigned* bits = has_bits(P, A) ? bits_of(lds) : nullptr;
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>());
+        unsigned* bits = has_bits(P, A) ? bits_of(P, A0, lds) : nullptr;
         if (bits) {
             // the atom just subtracted made its span possibly non-zero (utils.py:76-131)
             int s, e, es;
@@ -366,7 +410,7 @@ template <typename R> struct SparseRecorr {
 // initial correlation of a sparse multi-feature input (modeling.py:1077): only rows whose window
 // contains a non-zero input row can be non-zero; everything else is (c = 0, k = 0).
 //   grid = (B, nsplit): workgroup (b, y) owns a contiguous range of (2W-1)-row blocks of signal b;
-//   block = kThreads;  dynamic LDS = SparseLds<R> + T bits of row flags.
+//   block = kThreads;  dynamic LDS = SparseLds<R> + staged dictionary lists + T bits of row flags.
 //   A.scratch needs B * nsplit tables.
 // ------------------------------------------------------------------------------------------------
 template <typename R>
@@ -374,9 +418,10 @@ __global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P,
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(smem);
-    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + sparse_lds_bytes<R>());   // [ceil(T/32)]
+    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + sparse_lds_bytes<R>() + staged_dict_bytes(P, A0));   // [ceil(T/32)]
     const int b = blockIdx.x, tid = threadIdx.x, T = P.T, W = P.W, F = P.F;
-    SparseArgs<R> A = A0;
+    stage_dict(P, A0, smem + sparse_lds_bytes<R>());                      // (ordered by the barrier below)
+    SparseArgs<R> A = dict_view(P, A0, smem + sparse_lds_bytes<R>());
     A.scratch = A0.scratch + ((int64_t)blockIdx.y * gridDim.x) * (2 * W - 1) * P.K;   // sparse_rows adds blockIdx.x tables
     Sig<R> G{};
     G.r = S.residual + (int64_t)b * T * F;
