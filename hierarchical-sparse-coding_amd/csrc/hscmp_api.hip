@@ -39,6 +39,9 @@ struct hscmp_ctx {
     int* d_fptr = nullptr;    // the same non-zeros grouped by feature
     int* d_fkw = nullptr;
     void* d_fval = nullptr;
+    int* d_rl_cnt = nullptr;  // per-row feature lists of the residual's possibly non-zero cells (sparse dictionaries)
+    int* d_rl_f = nullptr;
+    bool rl_filled = false;   // the lists of the current input were written by the level chaining
     unsigned char* d_rowflag = nullptr;  // [B][T] non-zero input rows handed over by the level chaining
     bool rowflag_valid = false;
     size_t Dfrag_bytes = 0;
@@ -46,7 +49,7 @@ struct hscmp_ctx {
     int B = 0, T = 0, cap = 0, maxsel = 0;
     bool have_batch = false;
     size_t caps[16] = {0};
-    size_t cap_scratch = 0, cap_rowflag = 0;
+    size_t cap_scratch = 0, cap_rowflag = 0, cap_rl_cnt = 0, cap_rl_f = 0;
     void* d_x = nullptr;      // staging for host inputs
     void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
@@ -113,7 +116,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 
 static void free_all(hscmp_ctx* c)
 {
-    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
+    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
                     c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -285,6 +288,14 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
 // every buffer tracks its own capacity in bytes (element size changes with the dictionary dtype)
 struct BufCap { void** p; size_t* cap; size_t bytes; };
 
+// Per-row feature lists: multi-feature inputs with a sparse dictionary (the per-atom lists tell which cells an
+// atom touches).
+constexpr int kRowListCap = 8;
+static bool use_row_lists(const hscmp_ctx* ctx)
+{
+    return ctx->F > 1 && ctx->d_nzptr != nullptr && !getenv("HSCMP_NO_ROW_LISTS") && !getenv("HSCMP_FORCE_DENSE");
+}
+
 // Workgroups per signal of the sparse initial correlation: enough to fill the chip at small batches.
 static int sparse_init_split(int B, int T, int W)
 {
@@ -315,6 +326,8 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_edge, &ctx->caps[15], B * 2 * sizeof(unsigned long long)},
         {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)sparse_init_split(P.B, P.T, P.W) * (2 * P.W - 1) * P.K * es : 0},
         {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, ctx->F > 1 ? B * T : 0},
+        {(void**)&ctx->d_rl_cnt, &ctx->cap_rl_cnt, use_row_lists(ctx) ? B * T * sizeof(int) : 0},
+        {(void**)&ctx->d_rl_f, &ctx->cap_rl_f, use_row_lists(ctx) ? B * T * kRowListCap * sizeof(int) : 0},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -371,6 +384,9 @@ template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)
     A.nzptr = ctx->d_nzptr; A.nzwf = ctx->d_nzwf; A.nzval = (const R*)ctx->d_nzval;
     A.fptr = getenv("HSCMP_NO_PAIRING") ? nullptr : ctx->d_fptr; A.fkw = ctx->d_fkw; A.fval = (const R*)ctx->d_fval;
     A.nnz = ctx->dict_nnz; A.wts = (const R*)ctx->d_w;
+    A.caps = sparse_caps(ctx->W);
+    const bool lists = use_row_lists(ctx) && ctx->d_rl_cnt != nullptr;
+    A.rl_cnt = lists ? ctx->d_rl_cnt : nullptr; A.rl_f = ctx->d_rl_f; A.rl_cap = kRowListCap; A.rl_filled = ctx->rl_filled ? 1 : 0;
     return A;
 }
 
@@ -391,7 +407,7 @@ template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const D
 {
     State<R> S = make_state<R>(ctx);
     const SparseArgs<R> A = sparse_args<R>(ctx, P.T);
-    const size_t lds = sparse_lds_bytes<R>() + staged_dict_bytes(P, A) + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
+    const size_t lds = sparse_lds_bytes<R>(A.caps) + staged_dict_bytes(P, A) + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
     auto kern = corr_init_sparse_kernel<R>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(P.B, sparse_init_split(P.B, P.T, P.W)), dim3(kThreads), lds, ctx->stream, P, S, A);
@@ -419,6 +435,14 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     if (use_mfma(ctx, P.T)) {
         int rc = mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
         if (rc == 0) mf = true;
+    }
+    if (!mf && use_sparse_loop(ctx) && use_row_lists(ctx) && !ctx->rl_filled) {
+        // per-row lists of the input's non-zero cells (the level chaining writes them while it scatters)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_cnt, 0, (size_t)P.B * P.T * sizeof(int), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_f, 0xff, (size_t)P.B * P.T * kRowListCap * sizeof(int), ctx->stream));
+        const int split = std::max(1, std::min(256, 4096 / P.B));
+        hipLaunchKernelGGL((build_row_lists_kernel<R>), dim3(P.B, split), dim3(kThreads), 0, ctx->stream, (const R*)x_dev, P.T, P.F,
+                           ctx->d_rl_cnt, ctx->d_rl_f, kRowListCap);
     }
     const bool spi = !mf && use_sparse_init(ctx, P.T);
     if (spi) { int rc = launch_corr_init_sparse<R>(ctx, P); if (rc) return rc; }
@@ -496,14 +520,20 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     const size_t bytes = (size_t)count * T * ctx->F * sizeof(double);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_x, 0, bytes, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_rowflag, 0, (size_t)count * T, ctx->stream));
+    const bool lists = use_sparse_loop(ctx) && use_row_lists(ctx);
+    if (lists) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_cnt, 0, (size_t)count * T * sizeof(int), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_f, 0xff, (size_t)count * T * kRowListCap * sizeof(int), ctx->stream));
+    }
     const int has_min = !std::isnan(min_coefficients);
     hipLaunchKernelGGL((scatter_slots_kernel<double>), dim3(count), dim3(kThreads), 0, ctx->stream, (double*)ctx->d_x, T, ctx->F,
                        prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
-                       has_min ? min_coefficients : 0.0, ctx->d_rowflag);
+                       has_min ? min_coefficients : 0.0, ctx->d_rowflag, lists ? ctx->d_rl_cnt : nullptr, ctx->d_rl_f, kRowListCap);
     ctx->P = P; ctx->last = *params; ctx->B = count; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
     ctx->rowflag_valid = true;                  // the sparse initial correlation skips its scan of the dense input
+    ctx->rl_filled = lists;
     rc = run_encode<double>(ctx, P, ctx->d_x);
-    ctx->rowflag_valid = false;
+    ctx->rowflag_valid = false; ctx->rl_filled = false;
     if (rc) return rc;
     ctx->have_batch = true;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -722,6 +752,13 @@ extern "C" int hscmp_debug_blocks(unsigned long long* out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(hscmp::g_blk), (size_t)n * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 // diagnostic build only
+extern "C" int hscmp_debug_counters(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hscmp::g_cnt), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hscmp::g_cnt), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+
 extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
 {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hscmp::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

@@ -95,7 +95,8 @@ template <typename R>
 __global__ __launch_bounds__(kThreads) void scatter_slots_kernel(R* __restrict__ x, int T, int F, const int* __restrict__ slot_t,
                                                                  const int* __restrict__ slot_k, const double* __restrict__ slot_a,
                                                                  const int* __restrict__ stats, int cap, int first, int has_min, double minc,
-                                                                 unsigned char* __restrict__ rowflag)
+                                                                 unsigned char* __restrict__ rowflag, int* __restrict__ rl_cnt,
+                                                                 int* __restrict__ rl_f, int rl_cap)
 {
     const int b = blockIdx.x, src = first + b;
     const int n = stats[(int64_t)src * ST_COUNT + ST_SLOTS];
@@ -105,6 +106,30 @@ __global__ __launch_bounds__(kThreads) void scatter_slots_kernel(R* __restrict__
         const int t = slot_t[(int64_t)src * cap + i];
         x[((int64_t)b * T + t) * F + slot_k[(int64_t)src * cap + i]] = (R)a;
         rowflag[(int64_t)b * T + t] = 1;                   // non-zero input row (rowflag must be zero filled)
+        if (rl_cnt) {                                      // per-row list of the features that may be non-zero
+            const int c = atomicAdd(&rl_cnt[(int64_t)b * T + t], 1);
+            if (c < rl_cap) rl_f[((int64_t)b * T + t) * rl_cap + c] = slot_k[(int64_t)src * cap + i];
+        }
+    }
+}
+
+// Per-row feature lists of a dense multi-feature input x [B][T][F]: rl_cnt[b][t] = number of non-zero
+// features of row t (may exceed rl_cap: the row is then treated as dense), rl_f[b][t][0..rl_cap) their
+// indices in any order (-1 = empty; both arrays must be pre-filled with 0 / -1).
+//   grid = (B, splits), block = kThreads
+template <typename R>
+__global__ __launch_bounds__(kThreads) void build_row_lists_kernel(const R* __restrict__ x, int T, int F, int* __restrict__ rl_cnt,
+                                                                   int* __restrict__ rl_f, int rl_cap)
+{
+    const int b = blockIdx.x;
+    const int64_t n = (int64_t)T * F;
+    const R* xb = x + (int64_t)b * n;
+    for (int64_t e = (int64_t)blockIdx.y * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.y * kThreads) {
+        if (xb[e] != (R)0) {
+            const int t = (int)(e / F), f = (int)(e - (int64_t)t * F);
+            const int c = atomicAdd(&rl_cnt[(int64_t)b * T + t], 1);
+            if (c < rl_cap) rl_f[((int64_t)b * T + t) * rl_cap + c] = f;
+        }
     }
 }
 
@@ -329,7 +354,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G,
-                                               SH& sh, const Args&, char* lds, int p)
+                                               SH& sh, const Args&, char* lds, int p, int)
     {
         const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x;
         const int nrows = 2 * W - 1;
@@ -694,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
 
             if constexpr (!Recorr::kFused) HSCMP_STAMP(2);
             // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
-            Recorr::run(P, S, G, sh, A, plds, p);
+            Recorr::run(P, S, G, sh, A, plds, p, k);
             __syncthreads();
             if constexpr (!Recorr::kFused) HSCMP_STAMP(3);
 

@@ -608,7 +608,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
 
     // never reached: iterate_kernel hands the whole atom body to apply_atom() when kFused
     template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams&, const State<R>&, const Sig<R>&, SH&, const Args&, char*, int) {}
+    static __device__ __forceinline__ void run(const DevParams&, const State<R>&, const Sig<R>&, SH&, const Args&, char*, int, int) {}
 
     // (k, c) of position t by ONE wave (blocked selection, modeling.py:935-946): the window goes to
     // this wave's private LDS strip, lanes stride over the atoms, first k wins ties.

@@ -8,7 +8,7 @@
 // c[t,k] runs the pinned fma chain over the gathered entries only.  A zero sample contributes
 // fma(0, d, acc) == acc to the dense chain, so skipping it is exact (up to the sign of a zero
 // result); the (f outer, w inner) order of the pinned chain is the (feature, row) sort order.
-// Windows that are not sparse (more than kNzMax entries) fall back to the dense chain.
+// Windows that are not sparse (more entries than the LDS list holds) fall back to the dense chain.
 //
 // Level dictionaries built from decompositions (hsc/dataset.py:137-194, a few lower-level events per
 // atom plus the unit "singleton" atoms of :826-860) are themselves almost all zero.  For those only
@@ -16,9 +16,12 @@
 // dictionary non-zeros (k, w) of feature f, the pairs are sorted by (output, chain order) and one
 // thread per output runs its chain.  All other outputs are +0.
 //
-// A per-signal row-occupancy bitmap (which residual rows may hold a non-zero) keeps the gather from
-// touching the zero rows: it starts from the non-zero input rows and grows by the span of every
-// subtracted atom.
+// Finding the window's non-zeros is the expensive part (a window is (3W-2) x F values, 400 KB at
+// BASELINE config 5 level 2).  With a sparse dictionary the set of (row, feature) cells that can be
+// non-zero is tracked explicitly: per-row feature lists in global memory, filled from the input and
+// extended by the few cells every subtracted atom touches; the gather reads the lists and then exactly
+// those cells (two dependent round trips).  Rows whose list overflows are read densely.  Without
+// dictionary lists a per-signal row-occupancy bitmap at least skips the all-zero rows.
 //
 // Used for both the initial correlation (zero padded, modeling.py:1077) -- only rows within reach
 // of a non-zero input row can be non-zero -- and the local re-correlation after each atom
@@ -29,9 +32,22 @@
 
 namespace hscmp {
 
-constexpr int kNzMax = 256;             // gathered non-zeros per row block (LDS list)
-constexpr int kRecMax = 256;            // (input non-zero, dictionary non-zero) pairs per row block (<= 1024: 10-bit index)
-constexpr int kWinRowsMax = 256;        // occupied rows of one window (LDS list)
+// Capacities of the LDS lists of one row block, chosen per dictionary shape on the host (sparse_caps):
+struct SparseCaps {
+    int nz;     // gathered non-zeros of the window
+    int rec;    // (input non-zero, dictionary non-zero) pairs; nz <= rec <= 1024 (10-bit index in the row arg-max)
+    int rows;   // occupied rows of the window (also the largest row count the bucketed pair sort handles)
+};
+inline SparseCaps sparse_caps(int W)
+{
+    // a window spans 3W-2 rows; room for about 2 input non-zeros and 8 pairs per row, within 128..512 / 256..1024
+    auto pow2 = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
+    SparseCaps c;
+    c.nz = std::min(512, std::max(128, pow2(2 * (3 * W - 2))));
+    c.rec = std::min(1024, std::max(256, pow2(8 * (3 * W - 2))));
+    c.rows = 256;
+    return c;
+}
 constexpr int kDictListMaxPerAtom = 32; // a dictionary with at most this many non-zeros per atom (average) gets per-atom lists
 constexpr int kRowBitsMaxT = 262144;    // longest signal with a row-occupancy bitmap in LDS (32 KB)
 
@@ -49,63 +65,108 @@ template <typename R> struct SparseArgs {
     const int* fptr;    // [F+1]
     const int* fkw;     // [nnz] (k << 16) | w
     const R* fval;      // [nnz]
+    // Per-row lists of the features that may be non-zero in the residual (sparse dictionaries only): the
+    // window gather reads them instead of scanning rows of F values.  nullptr: scan (row bitmap).
+    int* rl_cnt;        // [B][T] members of row t (> rl_cap: list overflowed, the row is read densely)
+    int* rl_f;          // [B][T][rl_cap] feature indices, -1 = empty
+    int rl_cap;         // power of two
+    int rl_filled;      // the caller (level chaining) has already listed the input's non-zeros
+    SparseCaps caps;    // LDS list capacities
     int nnz;            // non-zeros of the dictionary (length of the lists)
     const R* wts;       // atom weights (State::weights, or their LDS copy)
 };
 
-constexpr int kDictLdsBytes = 12288;    // by-feature lists + weights are copied to LDS when they fit this
+constexpr int kDictLdsBytes = 12288;    // the by-feature lists are copied to LDS when they fit this ...
+constexpr int kWeightLdsBytes = 8192;   // ... and so are the atom weights
 
-// LDS bytes of the staged by-feature lists + weights (0: they stay in global memory)
-template <typename R> __host__ __device__ inline size_t staged_dict_bytes(const DevParams& P, const SparseArgs<R>& A)
+template <typename R> __host__ __device__ inline size_t staged_weight_bytes(const DevParams& P, const SparseArgs<R>& A)
+{
+    const size_t b = (size_t)P.K * sizeof(R);
+    return (A.wts && b <= (size_t)kWeightLdsBytes) ? (b + 15) / 16 * 16 : 0;
+}
+template <typename R> __host__ __device__ inline size_t staged_list_bytes(const DevParams& P, const SparseArgs<R>& A)
 {
     if (!A.fptr) return 0;
-    const size_t b = (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8 + ((size_t)A.nnz + (A.wts ? (size_t)P.K : 0)) * sizeof(R);
+    const size_t b = (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8 + (size_t)A.nnz * sizeof(R);
     return b <= (size_t)kDictLdsBytes ? (b + 15) / 16 * 16 : 0;
 }
+// LDS bytes of the staged weights + by-feature lists (what does not fit stays in global memory)
+template <typename R> __host__ __device__ inline size_t staged_dict_bytes(const DevParams& P, const SparseArgs<R>& A)
+{
+    return staged_weight_bytes(P, A) + staged_list_bytes(P, A);
+}
 
-// Arguments whose lists / weights point at their LDS copies at `base` (unchanged when not staged).
+// Arguments whose lists / weights point at their LDS copies at `base` (unchanged for what is not staged).
 template <typename R>
 __device__ __forceinline__ SparseArgs<R> dict_view(const DevParams& P, const SparseArgs<R>& A, char* base)
 {
     SparseArgs<R> B = A;
-    if (staged_dict_bytes(P, A) == 0) return B;
-    int* fptr = reinterpret_cast<int*>(base);
-    R* fval = reinterpret_cast<R*>(base + (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8);
-    B.fptr = fptr; B.fkw = fptr + (P.F + 1); B.fval = fval;
-    if (A.wts) B.wts = fval + A.nnz;
+    const size_t wb = staged_weight_bytes(P, A);
+    if (wb) B.wts = reinterpret_cast<const R*>(base);
+    if (staged_list_bytes(P, A)) {
+        int* fptr = reinterpret_cast<int*>(base + wb);
+        B.fptr = fptr; B.fkw = fptr + (P.F + 1);
+        B.fval = reinterpret_cast<const R*>(base + wb + (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8);
+    }
     return B;
 }
 
-// Copy the lists to LDS at `base` (all threads; the caller synchronises).
+// Copy weights / lists to LDS at `base` (all threads; the caller synchronises).
 template <typename R>
 __device__ __forceinline__ void stage_dict(const DevParams& P, const SparseArgs<R>& A, char* base)
 {
-    if (staged_dict_bytes(P, A) == 0) return;
     const SparseArgs<R> B = dict_view(P, A, base);
-    for (int i = threadIdx.x; i <= P.F; i += kThreads) const_cast<int*>(B.fptr)[i] = A.fptr[i];
-    for (int i = threadIdx.x; i < A.nnz; i += kThreads) { const_cast<int*>(B.fkw)[i] = A.fkw[i]; const_cast<R*>(B.fval)[i] = A.fval[i]; }
-    if (A.wts) for (int i = threadIdx.x; i < P.K; i += kThreads) const_cast<R*>(B.wts)[i] = A.wts[i];
+    if (staged_weight_bytes(P, A)) for (int i = threadIdx.x; i < P.K; i += kThreads) const_cast<R*>(B.wts)[i] = A.wts[i];
+    if (staged_list_bytes(P, A)) {
+        for (int i = threadIdx.x; i <= P.F; i += kThreads) const_cast<int*>(B.fptr)[i] = A.fptr[i];
+        for (int i = threadIdx.x; i < A.nnz; i += kThreads) { const_cast<int*>(B.fkw)[i] = A.fkw[i]; const_cast<R*>(B.fval)[i] = A.fval[i]; }
+    }
 }
 
+// LDS lists of one row block: a view into the policy's dynamic LDS (sizes = SparseCaps).
 template <typename R> struct SparseLds {
-    R val[kNzMax];
-    int key[kNzMax];    // (f << 16) | local row j
-    R sval[kNzMax];     // sorted copies
-    int skey[kNzMax];
-    int count;
-    // occupied rows of the window: local row, global (reflected) row
-    int rowj[kWinRowsMax], rowg[kWinRowsMax];
-    int nwinrows;
+    int* ctl;                   // [0] gathered non-zeros, [1] occupied window rows, [2] pairs
+    R* val; int* key;           // [nz] gathered non-zeros: value, (f << 16) | local row j
+    int* rowj; int* rowg;       // [rows+1] occupied rows of the window: local row, global (reflected) row;
+                                //          reused by the pair sort as per-row counts / start offsets
     // pairing of a sparse window with a sparse dictionary: one record per non-zero product
-    unsigned long long rkey[kRecMax];   // row << 48 | k << 32 | f << 16 | w : output first, then chain order
-    R rx[kRecMax], rd[kRecMax];         // the two factors
-    int perm[kRecMax];                  // sorted position -> record
-    unsigned okey[kRecMax];             // per sorted position: row << 16 | k if it starts an output's chain, else ~0
-    R out[kRecMax];                     // chain result, at the chain's first sorted position
-    int nrec;
+    unsigned long long* rkey;   // [rec] row << 48 | k << 32 | f << 16 | w : output first, then chain order
+    R* rx; R* rd;               // [rec] the two factors
+    R* out;                     // [rec] chain result, at the chain's first sorted position
+    int* perm;                  // [rec] sorted position -> record
+    unsigned* okey;             // [rec] per sorted position: row << 16 | k if it starts an output's chain, else ~0
+    // gathered window x dense dictionary (never used together with the pairing): sorted copies
+    R* sval; int* skey;         // [nz], aliases of rx / perm
+    SparseCaps caps;
 };
 
-template <typename R> __host__ __device__ constexpr size_t sparse_lds_bytes() { return ((sizeof(SparseLds<R>) + 15) / 16) * 16; }
+__host__ __device__ inline size_t sparse_lds_bytes_of(const SparseCaps& c, size_t es)
+{
+    const size_t b = 16 + (size_t)c.nz * (es + 4) + (size_t)(c.rows + 1) * 8 + 8 + (size_t)c.rec * (8 + 3 * es + 8);
+    return (b + 15) / 16 * 16;
+}
+template <typename R> __host__ __device__ inline size_t sparse_lds_bytes(const SparseCaps& c) { return sparse_lds_bytes_of(c, sizeof(R)); }
+
+template <typename R> __device__ __forceinline__ SparseLds<R> sparse_lds_view(char* base, const SparseCaps& c)
+{
+    SparseLds<R> L;
+    L.caps = c;
+    L.ctl = reinterpret_cast<int*>(base);
+    char* p = base + 16;
+    L.rkey = reinterpret_cast<unsigned long long*>(p); p += (size_t)c.rec * 8;
+    L.rx = reinterpret_cast<R*>(p); p += (size_t)c.rec * sizeof(R);
+    L.rd = reinterpret_cast<R*>(p); p += (size_t)c.rec * sizeof(R);
+    L.out = reinterpret_cast<R*>(p); p += (size_t)c.rec * sizeof(R);
+    L.val = reinterpret_cast<R*>(p); p += (size_t)c.nz * sizeof(R);
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 7) & ~(uintptr_t)7);
+    L.perm = reinterpret_cast<int*>(p); p += (size_t)c.rec * 4;
+    L.okey = reinterpret_cast<unsigned*>(p); p += (size_t)c.rec * 4;
+    L.key = reinterpret_cast<int*>(p); p += (size_t)c.nz * 4;
+    L.rowj = reinterpret_cast<int*>(p); p += (size_t)(c.rows + 1) * 4;
+    L.rowg = reinterpret_cast<int*>(p);
+    L.sval = L.rx; L.skey = L.perm;
+    return L;
+}
 
 // Dense chain for output rows [row0, row0+nrows) (global positions), all atoms: the generic
 // fallback.  reflect: np.pad 'reflect' w.r.t. the slice [sidx, sidx+nslice) (modeling.py:1046);
@@ -134,39 +195,89 @@ __device__ __forceinline__ void dense_rows_to_table(const DevParams& P, const R*
     }
 }
 
+// The list counters are advanced with atomics (performed in L2): read them past the vector L1 as well.
+__device__ __forceinline__ int list_count(const int* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Non-zeros of the residual rows [g0, g0+nwin) (reflected / zero padded) -> L.val / L.key, in any
-// order.  rowbits (LDS, may be nullptr): only rows whose bit is set are read.  Returns the number
-// of non-zeros found (> kNzMax: the list overflowed and is unusable).  Contains barriers.
+// order.  With per-row feature lists (A.rl_cnt) only the listed cells are read; otherwise rows are scanned,
+// and with rowbits (LDS, may be nullptr) only those whose bit is set.  Returns the number
+// of non-zeros found (> caps.nz: the list overflowed and is unusable).  Contains barriers.
 template <typename R>
-__device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G, SparseLds<R>& L, const unsigned* rowbits,
-                                             int g0, int nwin, bool reflect, int sidx, int nslice)
+__device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G, const SparseArgs<R>& A, const SparseLds<R>& L,
+                                             const unsigned* rowbits, int g0, int nwin, bool reflect, int sidx, int nslice)
 {
     const int T = P.T, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { L.count = 0; L.nrec = 0; L.nwinrows = 0; }
+    const int nzcap = L.caps.nz, rowcap = L.caps.rows;
+    if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; }
     __syncthreads();
-    // rows that exist (zero padding) and may hold a non-zero
-    for (int j = tid; j < nwin; j += kThreads) {
-        int g = g0 + j;
-        bool ok = true;
-        if (reflect) g = reflect_index(g, sidx, nslice);
-        else ok = g >= 0 && g < T;
-        if (ok && rowbits) ok = ((rowbits[g >> 5] >> (g & 31)) & 1u) != 0;
-        if (ok) {
-            const int o = atomicAdd(&L.nwinrows, 1);
-            if (o < kWinRowsMax) { L.rowj[o] = j; L.rowg[o] = g; }
+    if (A.rl_cnt) {
+        // listed cells: items = (window row, list slot); first the feature indices, then the values
+        const int C = A.rl_cap, shift = __ffs(C) - 1;
+        const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
+        const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
+        constexpr int kV = 4;
+        const int items = nwin << shift;
+        for (int it0 = tid; it0 < items; it0 += kThreads * kV) {
+            int g[kV], f[kV], j[kV], n[kV];
+#pragma unroll
+            for (int u = 0; u < kV; ++u) {
+                const int it = it0 + u * kThreads;
+                f[u] = -1; n[u] = 0; g[u] = 0; j[u] = it >> shift;
+                if (it < items) {
+                    int gg = g0 + j[u];
+                    bool ok = true;
+                    if (reflect) gg = reflect_index(gg, sidx, nslice);
+                    else ok = gg >= 0 && gg < T;
+                    if (ok) { g[u] = gg; n[u] = list_count(cnt + gg); f[u] = lf[((int64_t)gg << shift) + (it & (C - 1))]; }
+                }
+            }
+            R v[kV];
+#pragma unroll
+            for (int u = 0; u < kV; ++u) {
+                v[u] = (R)0;
+                if (n[u] > C) {                       // overflowed list: the row goes to the dense scan below (once)
+                    if (((it0 + u * kThreads) & (C - 1)) == 0) {
+                        const int o = atomicAdd(&L.ctl[1], 1);
+                        if (o < rowcap) { L.rowj[o] = j[u]; L.rowg[o] = g[u]; }
+                    }
+                } else if (f[u] >= 0) v[u] = G.r[(int64_t)g[u] * F + f[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kV; ++u)
+                if (v[u] != (R)0) {
+                    const int o = atomicAdd(&L.ctl[0], 1);
+                    if (o < nzcap) { L.val[o] = v[u]; L.key[o] = (f[u] << 16) | j[u]; }
+                }
+        }
+    } else {
+        // rows that exist (zero padding) and may hold a non-zero
+        for (int j = tid; j < nwin; j += kThreads) {
+            int g = g0 + j;
+            bool ok = true;
+            if (reflect) g = reflect_index(g, sidx, nslice);
+            else ok = g >= 0 && g < T;
+            if (ok && rowbits) ok = ((rowbits[g >> 5] >> (g & 31)) & 1u) != 0;
+            if (ok) {
+                const int o = atomicAdd(&L.ctl[1], 1);
+                if (o < rowcap) { L.rowj[o] = j; L.rowg[o] = g; }
+            }
         }
     }
     __syncthreads();
-    const int nr = L.nwinrows;
-    if (nr > kWinRowsMax) return kNzMax + 1;
-    // (row, 64-feature chunk) items round-robin over the waves, four loads in flight per lane
+    const int nr = L.ctl[1];
+    if (nr > rowcap) return nzcap + 1;
+    // (row, 64-feature chunk) items round-robin over the waves, eight loads in flight per lane
+    constexpr int kU = 8;
     const int nchunks = (F + 63) >> 6;
     const int items = nr * nchunks;
-    for (int it0 = wv; it0 < items; it0 += kWaves * 4) {
-        R v[4];
-        int key[4];
+    for (int it0 = wv; it0 < items; it0 += kWaves * kU) {
+        R v[kU];
+        int key[kU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const int it = it0 + u * kWaves;
             v[u] = (R)0; key[u] = 0;
             if (it < items) {
@@ -175,32 +286,36 @@ __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kU; ++u)
             if (v[u] != (R)0) {
-                const int o = atomicAdd(&L.count, 1);
-                if (o < kNzMax) { L.val[o] = v[u]; L.key[o] = key[u]; }
+                const int o = atomicAdd(&L.ctl[0], 1);
+                if (o < nzcap) { L.val[o] = v[u]; L.key[o] = key[u]; }
             }
     }
     __syncthreads();
-    return L.count;
+    return L.ctl[0];
 }
 
 // Rows [row0, row0+nrows) x all atoms -> per-position best (best_c, best_k), sparsity aware.
 //   nrows <= 2W-1 (table capacity).  All threads of the workgroup call it (contains barriers).
 template <typename R>
 __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& S, const Sig<R>& G, const SparseArgs<R>& A,
-                                            SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
+                                            const SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
                                             int sidx, int nslice)
 {
     const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nzcap = L.caps.nz, reccap = L.caps.rec;
     R* tab = A.scratch + (int64_t)blockIdx.x * (2 * W - 1) * K;
     const int nwin = nrows + W - 1;                 // residual rows the block can see
     const int g0 = row0 - P.off;                    // global row of local row 0
 
     // ---- 1. the non-zeros of the window (any order)
-    const int n = gather_window(P, G, L, rowbits, g0, nwin, reflect, sidx, nslice);
+    HSCMP_STAMP_BEGIN();
+    const int n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
+    HSCMP_STAMP(8);
+    HSCMP_TALLY(0, 1); HSCMP_TALLY(1, n); HSCMP_TALLY(2, n > nzcap); HSCMP_TALLY(5, L.ctl[1]);
 
-    if (A.fptr && n <= kNzMax) {
+    if (A.fptr && n <= nzcap) {
         // ---- sparse window x sparse dictionary: only the non-zero products are formed.
         //  a. pair every input non-zero (f, j) with the dictionary non-zeros (k, w) of feature f: output row j - w
         for (int i = tid; i < n; i += kThreads) {
@@ -212,8 +327,8 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 if (row < 0 || row >= nrows) continue;
                 const int t = row0 + row;
                 if (t < 0 || t >= T) continue;
-                const int o = atomicAdd(&L.nrec, 1);
-                if (o < kRecMax) {
+                const int o = atomicAdd(&L.ctl[2], 1);
+                if (o < reccap) {
                     L.rkey[o] = ((unsigned long long)row << 48) | ((unsigned long long)((unsigned)kw >> 16) << 32) |
                                 ((unsigned long long)f << 16) | (unsigned)w;
                     L.rx[o] = v; L.rd[o] = A.fval[e];
@@ -221,16 +336,57 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             }
         }
         __syncthreads();
-        const int m = L.nrec;
-        if (m <= kRecMax) {
-            //  b. sort by (output, chain order): rank sort, the keys are distinct
-            for (int i = tid; i < m; i += kThreads) {
-                const unsigned long long key = L.rkey[i];
-                int rank = 0;
-                for (int q = 0; q < m; ++q) rank += (L.rkey[q] < key) ? 1 : 0;
-                L.perm[rank] = i;
+        const int m = L.ctl[2];
+        HSCMP_STAMP(9);
+        HSCMP_TALLY(3, m); HSCMP_TALLY(4, m > reccap);
+        if (m <= reccap) {
+            //  b. sort by (output, chain order); the keys are distinct.  Few output rows: bucket by row first
+            //     (counts -> offsets -> members), then rank inside the bucket; otherwise one rank sort over all.
+            const bool bucketed = nrows <= L.caps.rows && m > 64;
+            int* cnt = L.rowj;                       // [nrows]   (the window-row lists are dead by now)
+            int* start = L.rowg;                     // [nrows+1]
+            if (bucketed) {
+                for (int r = tid; r < nrows; r += kThreads) cnt[r] = 0;
+                __syncthreads();
+                for (int i = tid; i < m; i += kThreads) atomicAdd(&cnt[(int)(L.rkey[i] >> 48)], 1);
+                __syncthreads();
+                if (wv == 0) {
+                    // exclusive prefix sum over the rows by one wave: each lane owns a run of rows
+                    const int per = (nrows + 63) >> 6;
+                    int local = 0;
+                    for (int q = 0; q < per; ++q) { const int r = lane * per + q; if (r < nrows) local += cnt[r]; }
+                    int incl = local;
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                    int run = incl - local;
+                    for (int q = 0; q < per; ++q) { const int r = lane * per + q; if (r < nrows) { start[r] = run; run += cnt[r]; } }
+                    if (lane == 63) start[nrows] = incl;
+                }
+                __syncthreads();
+                for (int r = tid; r < nrows; r += kThreads) cnt[r] = 0;          // cursors
+                __syncthreads();
+                unsigned* member = L.okey;           // bucket members (record indices); okey proper is written in step c
+                for (int i = tid; i < m; i += kThreads) {
+                    const int r = (int)(L.rkey[i] >> 48);
+                    member[start[r] + atomicAdd(&cnt[r], 1)] = (unsigned)i;
+                }
+                __syncthreads();
+                for (int i = tid; i < m; i += kThreads) {
+                    const unsigned long long key = L.rkey[i];
+                    const int r = (int)(key >> 48), b0 = start[r], b1 = start[r + 1];
+                    int rank = 0;
+                    for (int q = b0; q < b1; ++q) rank += (L.rkey[member[q]] < key) ? 1 : 0;
+                    L.perm[b0 + rank] = i;
+                }
+            } else {
+                for (int i = tid; i < m; i += kThreads) {
+                    const unsigned long long key = L.rkey[i];
+                    int rank = 0;
+                    for (int q = 0; q < m; ++q) rank += (L.rkey[q] < key) ? 1 : 0;
+                    L.perm[rank] = i;
+                }
             }
             __syncthreads();
+            HSCMP_STAMP(10);
             //  c. one chain per output, run by the thread of its first record (f outer, w inner from +0)
             for (int sp = tid; sp < m; sp += kThreads) {
                 const unsigned ok = (unsigned)(L.rkey[L.perm[sp]] >> 32);
@@ -248,32 +404,28 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 L.okey[sp] = mark;
             }
             __syncthreads();
-            //  d. per-row best over atoms: the listed outputs against the zeros of all the others
-            //     (a zero score never beats k = 0, the first of the ties)
-            for (int row = wv; row < nrows; row += kWaves) {
+            HSCMP_STAMP(11);
+            //  d. per-row best over atoms, one thread per row: the listed outputs (ascending k inside a row) against
+            //     the zeros of all the others -- a zero score never beats k = 0, the first of the ties
+            for (int row = tid; row < nrows; row += kThreads) {
                 const int t = row0 + row;
                 if (t < 0 || t >= T) continue;                       // overlapReplace clipping (utils.py:133-161)
-                Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
-                int at0 = -1;
-                for (int sp = lane; sp < m; sp += 64) {
+                const int b0 = bucketed ? start[row] : 0, b1 = bucketed ? start[row + 1] : m;
+                R bs = (R)0, c = (R)0;
+                int k = 0;
+                for (int sp = b0; sp < b1; ++sp) {
                     const unsigned ok = L.okey[sp];
                     if (ok == ~0u || (int)(ok >> 16) != row) continue;
-                    const int k = (int)(ok & 0xffffu);
-                    if (k == 0) at0 = sp;
-                    Cand<R> o; o.s = score_of(L.out[sp], k, A.wts); o.i = (k << 10) | sp;
-                    if (better(o, best)) best = o;
+                    const int kk = (int)(ok & 0xffffu);
+                    const R o = L.out[sp];
+                    if (kk == 0) c = o;                              // the value of the default winner
+                    const R sc = score_of(o, kk, A.wts);
+                    if (sc > bs) { bs = sc; k = kk; c = o; }
                 }
-                best = wave_argmax(best);
-                const unsigned long long has0 = __ballot(at0 >= 0);
-                R c; int k;
-                if (best.i != INT_MAX && best.s > (R)0) { k = best.i >> 10; c = L.out[best.i & 1023]; }
-                else {
-                    k = 0; c = (R)0;
-                    if (has0) { const int sp0 = __shfl(at0, __ffsll((long long)has0) - 1); c = L.out[sp0]; }
-                }
-                if (lane == 0) { G.bc[t] = c; G.bk[t] = k; }
+                G.bc[t] = c; G.bk[t] = k;
             }
             __syncthreads();
+            HSCMP_STAMP(12);
             return;
         }
     }
@@ -297,7 +449,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             }
             tab[o] = acc;
         }
-    } else if (n > kNzMax) {
+    } else if (n > nzcap) {
         dense_rows_to_table(P, G.r, S.D, row0, nrows, reflect, sidx, nslice, tab);
     } else {
         // ---- 2. sort by (feature, row): the pinned chain order f outer / w inner (rank sort)
@@ -346,9 +498,9 @@ template <typename R> struct SparseRecorr {
     static constexpr bool kScoreOnly = false;
     using Shared = IterSharedT<R, kMaxSegments, false>;
     using Args = SparseArgs<R>;
-    static __host__ __device__ bool has_bits(const DevParams& P, const Args& A) { return A.rowflag != nullptr && P.T <= kRowBitsMaxT; }
+    static __host__ __device__ bool has_bits(const DevParams& P, const Args& A) { return A.rl_cnt == nullptr && A.rowflag != nullptr && P.T <= kRowBitsMaxT; }
     // policy LDS: SparseLds | staged dictionary lists + weights (when small) | row bitmap (when T allows)
-    static __host__ __device__ size_t bits_offset(const DevParams& P, const Args& A) { return sparse_lds_bytes<R>() + staged_dict_bytes(P, A); }
+    static __host__ __device__ size_t bits_offset(const DevParams& P, const Args& A) { return sparse_lds_bytes<R>(A.caps) + staged_dict_bytes(P, A); }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A)
     {
         return bits_offset(P, A) + (has_bits(P, A) ? (size_t)((P.T + 31) / 32) * sizeof(unsigned) : 0);
@@ -356,13 +508,13 @@ template <typename R> struct SparseRecorr {
     static __device__ __forceinline__ unsigned* bits_of(const DevParams& P, const Args& A, char* lds) { return reinterpret_cast<unsigned*>(lds + bits_offset(P, A)); }
     static __device__ __forceinline__ const R* weights(const DevParams& P, const State<R>&, const Args& A, char* lds)
     {
-        return dict_view(P, A, lds + sparse_lds_bytes<R>()).wts;
+        return dict_view(P, A, lds + sparse_lds_bytes<R>(A.caps)).wts;
     }
     // the row-occupancy bitmap of this signal: flags written by the initial correlation (or an earlier launch)
     static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>&, const Args& A, char* lds)
     {
-        stage_dict(P, A, lds + sparse_lds_bytes<R>());
-        if (!has_bits(P, A)) { __syncthreads(); return; }
+        stage_dict(P, A, lds + sparse_lds_bytes<R>(A.caps));
+        if (!has_bits(P, A)) { __syncthreads(); return; }                  // (row lists need no per-launch state)
         unsigned* bits = bits_of(P, A, lds);
         const unsigned char* rf = A.rowflag + (int64_t)blockIdx.x * P.T;
         const int nwords = (P.T + 31) / 32;
@@ -386,13 +538,31 @@ template <typename R> struct SparseRecorr {
                                                         int, int, int&, R&) {}
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
-                                               char* lds, int p)
+                                               char* lds, int p, int k)
     {
-        SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(lds);
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
         const int T = P.T, W = P.W;
-        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>());
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
         unsigned* bits = has_bits(P, A) ? bits_of(P, A0, lds) : nullptr;
-        if (bits) {
+        if (A.rl_cnt) {
+            // the cells the subtracted atom touched may be non-zero now: add them to their rows' lists
+            // (distinct (w, f) of one atom are distinct cells, so no two threads append the same member)
+            const int C = A.rl_cap;
+            int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
+            int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
+            const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1];
+            for (int e = e0 + (int)threadIdx.x; e < e1; e += kThreads) {
+                const int wf = A.nzwf[e], f = wf & 0xffff, g = p - P.off + (wf >> 16);
+                if (g < 0 || g >= T) continue;                         // clipped part of the atom (utils.py:110-129)
+                const int n = list_count(cnt + g);
+                bool listed = n > C;                                    // an overflowed row is read densely anyway
+                for (int q = 0; q < min(n, C) && !listed; ++q) listed = lf[(int64_t)g * C + q] == f;
+                if (!listed) {
+                    const int o = atomicAdd(&cnt[g], 1);
+                    if (o < C) lf[(int64_t)g * C + o] = f;
+                }
+            }
+        } else if (bits) {
             // the atom just subtracted made its span possibly non-zero (utils.py:76-131)
             int s, e, es;
             centered_span(T, W, p, s, e, es);
@@ -417,11 +587,11 @@ template <typename R>
 __global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P, State<R> S, SparseArgs<R> A0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SparseLds<R>& L = *reinterpret_cast<SparseLds<R>*>(smem);
-    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + sparse_lds_bytes<R>() + staged_dict_bytes(P, A0));   // [ceil(T/32)]
+    const SparseLds<R> L = sparse_lds_view<R>(smem, A0.caps);
+    unsigned* rowbits = reinterpret_cast<unsigned*>(smem + sparse_lds_bytes<R>(A0.caps) + staged_dict_bytes(P, A0));   // [ceil(T/32)]
     const int b = blockIdx.x, tid = threadIdx.x, T = P.T, W = P.W, F = P.F;
-    stage_dict(P, A0, smem + sparse_lds_bytes<R>());                      // (ordered by the barrier below)
-    SparseArgs<R> A = dict_view(P, A0, smem + sparse_lds_bytes<R>());
+    stage_dict(P, A0, smem + sparse_lds_bytes<R>(A0.caps));               // (ordered by the barrier below)
+    SparseArgs<R> A = dict_view(P, A0, smem + sparse_lds_bytes<R>(A0.caps));
     A.scratch = A0.scratch + ((int64_t)blockIdx.y * gridDim.x) * (2 * W - 1) * P.K;   // sparse_rows adds blockIdx.x tables
     Sig<R> G{};
     G.r = S.residual + (int64_t)b * T * F;
@@ -439,7 +609,10 @@ __global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P,
     __syncthreads();
     // input rows with a non-zero sample: handed over by the level chaining, or found by a scan
     unsigned char* rf = A.rowflag ? A.rowflag + (int64_t)b * T : nullptr;
-    if (rf && A.rowflag_filled) {
+    if (A.rl_cnt) {
+        const int* cnt = A.rl_cnt + (int64_t)b * T;
+        for (int t = in_lo + tid; t < in_hi; t += kThreads) if (cnt[t] > 0) atomicOr(&rowbits[t >> 5], 1u << (t & 31));
+    } else if (rf && A.rowflag_filled) {
         for (int t = in_lo + tid; t < in_hi; t += kThreads) if (rf[t]) atomicOr(&rowbits[t >> 5], 1u << (t & 31));
     } else {
         const int64_t e0 = (int64_t)in_lo * F, e1 = (int64_t)in_hi * F;
@@ -447,7 +620,7 @@ __global__ __launch_bounds__(kThreads) void corr_init_sparse_kernel(DevParams P,
             if (G.r[e] != (R)0) atomicOr(&rowbits[(int)(e / F) >> 5], 1u << ((int)(e / F) & 31));
     }
     __syncthreads();
-    if (rf && !A.rowflag_filled)                         // publish the flags of the owned rows for the greedy loop
+    if (rf && !A.rowflag_filled && !A.rl_cnt)            // publish the flags of the owned rows for the greedy loop
         for (int t = r_lo + tid; t < r_hi; t += kThreads) rf[t] = (unsigned char)((rowbits[t >> 5] >> (t & 31)) & 1u);
     // walk the output rows in blocks of up to 2W-1; a block is computed iff some input row in its reach is set
     for (int row0 = r_lo; row0 < r_hi; row0 += blk) {

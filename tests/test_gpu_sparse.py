@@ -1,6 +1,7 @@
 """GPU parity (-m gpu) of the sparsity-aware multi-feature kernels (levels >= 1 of the hierarchical
 encoder, hsc/modeling.py:1427-1492) against the CPU oracle, bit for bit, on each of their three
-correlation strategies (and with / without the row-occupancy bitmap): sparse window x sparse dictionary pairing (default for level dictionaries),
+correlation strategies (and the three ways of finding a window's non-zeros: per-row feature lists,
+row-occupancy bitmap + scan, plain scan): sparse window x sparse dictionary pairing (default for level dictionaries),
 per-atom dictionary lists (HSCMP_NO_PAIRING), gathered window x dense dictionary (HSCMP_NO_DICT_LISTS)."""
 import numpy as np
 import pytest
@@ -8,7 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'paired': {}, 'atom_lists': {'HSCMP_NO_PAIRING': '1'}, 'gathered': {'HSCMP_NO_DICT_LISTS': '1'},
-            'paired_no_rowbits': {'HSCMP_NO_ROWBITS': '1'}}
+            'paired_row_scan': {'HSCMP_NO_ROW_LISTS': '1'},
+            'paired_no_rowbits': {'HSCMP_NO_ROW_LISTS': '1', 'HSCMP_NO_ROWBITS': '1'}}
 
 
 def _level_case(seed, T, F, K, W, dtype, nnz_atom=3, density=0.02, singletons=True):
@@ -45,6 +47,9 @@ CASES = [
     # dense inputs (seed >= 100): the window / pair lists overflow and the fallback chains run
     (100, 200, 16, 8, 16, np.float64, dict(nbNonzeroCoefs=25)),
     (101, 150, 40, 6, 12, np.float32, dict(toleranceSnr=3.0, nbBlocks=2)),
+    # a few dense rows in a sparse input (seed 200..): their feature lists overflow, the rows are read densely
+    (200, 400, 24, 10, 8, np.float64, dict(nbNonzeroCoefs=50)),
+    (201, 400, 24, 10, 8, np.float32, dict(toleranceSnr=25.0, nbBlocks=4)),
 ]
 
 
@@ -58,8 +63,12 @@ def test_level_shaped_problem_vs_oracle(case, variant, weighted, monkeypatch):
         monkeypatch.setenv(key, val)
     seed, T, F, K, W, dtype, kw = CASES[case]
     x, D = _level_case(seed, T, F, K, W, dtype)
-    if seed >= 100:
+    if 100 <= seed < 200:
         x = np.random.RandomState(seed).standard_normal((T, F)).astype(dtype)
+    elif seed >= 200:
+        rs = np.random.RandomState(seed)
+        for t in (50, 51, 200, 399):
+            x[t] = rs.standard_normal(F).astype(dtype)
     kw = dict(kw)
     if weighted:
         w = np.ones(D.shape[0], dtype=dtype)
@@ -93,6 +102,7 @@ def test_variants_are_the_ones_dispatched(monkeypatch):
     assert names['atom_lists'].startswith('dictlist_init+dictlist_loop')
     assert names['gathered'].startswith('sparse_init+gathered_loop')
     assert names['paired_no_rowbits'].startswith('dictlist_init+dictlist_loop')
+    assert names['paired_row_scan'].startswith('dictlist_init+dictlist_loop')
 
 
 def test_dense_level_dictionary_keeps_the_gathered_path():
@@ -112,7 +122,7 @@ def test_dense_level_dictionary_keeps_the_gathered_path():
     assert np.array_equal(residual, res)
 
 
-@pytest.mark.parametrize('variant', ['paired', 'gathered'])
+@pytest.mark.parametrize('variant', ['paired', 'paired_row_scan', 'gathered'])
 def test_resumed_launches_keep_the_row_bitmap(variant, monkeypatch):
     """A stopCondition callback splits the loop into one launch per round (hscmp_continue): the row
     flags written back by each launch must carry the spans of the atoms subtracted so far."""

@@ -10,6 +10,7 @@ from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
 
 B = int(os.environ.get('B', '8')); T = int(os.environ.get('T', '65536'))
 K0, W0, K1, W1 = 256, 64, 128, 16
+CONFIG5 = os.environ.get('CONFIG') == '5'
 rs = np.random.RandomState(11)
 D0 = synth.make_dictionary(K0, W0, seed=4)
 D1 = np.zeros((K1, W1, K0), dtype=np.float32)
@@ -28,11 +29,19 @@ for b in range(B):
         x[s:e] += c * rep1[i][es:ee]
     xs.append(x.astype(np.float32))
 xs = np.stack(xs)
+snr, blocks = [30.0, 40.0], 10
+if CONFIG5:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import generate_dataset as gd
+    mld = gd.build([32, 64, 128], 4.0, patience=100)
+    xs, _, _ = gd.signals(mld, B, T)
+    mld = mld.withSingletonBases()
+    snr = [30.0, 35.0, 35.0]
 lib = _native.load_library()
 out = (ctypes.c_ulonglong * 16)()
 hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
 lib.hscmp_debug_stamps(out, 1)
-coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, toleranceSnr=[30.0, 40.0], nbBlocks=10, singletonWeight=0.95)
+coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, toleranceSnr=snr, nbBlocks=blocks, singletonWeight=0.95)
 lib.hscmp_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
 n = max(v[14], 1)
@@ -44,3 +53,12 @@ print('workgroup 0: %d atoms' % n)
 for i, nm in enumerate(names):
     print('  %-28s %9.0f cycles/atom' % (nm, v[i] / n))
 print('  total %.0f cycles/atom' % (v[:8].sum() / n))
+sub = ['gather', 'pairing', 'sort', 'chains', 'row arg-max']
+for i, nm in enumerate(sub):
+    print('    re-correlation / %-14s %9.0f cycles/atom' % (nm, v[8 + i] / n))
+cnt = (ctypes.c_ulonglong * 16)()
+lib.hscmp_debug_counters(cnt, 1)
+c = np.array(list(cnt), dtype=np.float64)
+calls = max(c[0], 1)
+print('  sparse_rows calls %d (all levels >= 1 of workgroup 0, initial correlation included): window non-zeros %.1f avg (%d overflows), occupied rows %.1f, pairs %.1f avg (%d overflows)' % (
+    calls, c[1] / calls, c[2], c[5] / calls, c[3] / calls, c[4]))

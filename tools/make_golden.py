@@ -13,6 +13,9 @@ Files written:
   tests/golden/cmp_config.npz   -- BASELINE config 1 (T=4096) and 8 full-size config-2 signals
                                    (T=65536, K=256, W=64, L0=256): outputs + input digests
   tests/golden/locomp_small.npz -- LoCOMP (modeling.py:1191-1425) on small seeded problems
+  tests/golden/synth_small.npz  -- dataset synthesis (hsc/dataset.py:412-796) under fixed numpy seeds: generated
+                                   multilevel dictionaries (raw, representations, decompositions), Poisson
+                                   events with / without rate scaling, rendered signals
   tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
                                    singleton bases, representations, per-level coefficients, residual
 """
@@ -344,6 +347,45 @@ def gen_locomp():
     print('locomp_small.npz: %d cases' % len(names))
 
 
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from golden_util import SYNTH_CASES  # noqa: E402  (the case table is shared with tests/test_dataset_synthesis.py)
+
+
+def gen_synth():
+    """Dataset synthesis of the REAL reference under fixed seeds (the generators draw from numpy's global
+    RandomState)."""
+    ref = load_reference()
+    out = {'names': np.array(sorted(SYNTH_CASES))}
+    for name, (kw, dseed, rate, eseed, n) in sorted(SYNTH_CASES.items()):
+        np.random.seed(dseed)
+        mld = ref.dataset.MultilevelDictionaryGenerator().generate(**kw)
+        out[name + '__nlevels'] = np.int64(mld.getNbLevels())
+        out[name + '__singletons'] = np.int64(mld.hasSingletonBases)
+        for l in range(mld.getNbLevels()):
+            out['%s__raw%d' % (name, l)] = mld.dictionaries[l]
+            out['%s__rep%d' % (name, l)] = mld.representations[l]
+            if l > 0:
+                for j, entry in enumerate(mld.decompositions[l - 1]):
+                    for q, part in enumerate(entry):
+                        out['%s__dec%d_%d_%d' % (name, l, j, q)] = np.asarray(part)
+        rates = [rate] * mld.getNbLevels()
+        for tag, ratio in (('plain', None), ('scaled', 0.25)):
+            np.random.seed(eseed)
+            gen = ref.dataset.SignalGenerator(mld, rates)
+            res = gen.generateEvents(n, ratio)
+            events = res if ratio is None else res[0]
+            if ratio is not None:
+                out['%s__%s_rates' % (name, tag)] = np.asarray(res[1], dtype=np.float64)
+            for f in events.dtype.names:
+                out['%s__%s_ev_%s' % (name, tag, f)] = events[f]
+            out['%s__%s_signal' % (name, tag)] = gen.generateSignalFromEvents(events, nbSamples=n)
+            out['%s__%s_autolen' % (name, tag)] = np.int64(len(gen.generateSignalFromEvents(events)))
+        print('synth', name, [d.shape for d in mld.dictionaries], len(events), 'events')
+    path = os.path.join(OUT, 'synth_small.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def scipy_sparse(c):
     import scipy.sparse
     return c if scipy.sparse.issparse(c) else scipy.sparse.csc_matrix(c)
@@ -352,7 +394,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp', 'synth']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -363,3 +405,5 @@ if __name__ == '__main__':
         gen_hsc()
     if 'locomp' in which:
         gen_locomp()
+    if 'synth' in which:
+        gen_synth()
