@@ -22,7 +22,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
-           'hscmp_update_inner_products', 'hscmp_encode_batch',
+           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
@@ -78,6 +78,7 @@ def load_library():
     lib.hscmp_select_best_atoms.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, vp, vp, vp, vp, ci,
                                             ctypes.POINTER(ctypes.c_int32)]
     lib.hscmp_update_inner_products.argtypes = [vp, vp, vp, ci, ci]
+    lib.hscmp_assign_windows.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
@@ -196,6 +197,16 @@ class Engine(object):
         out = np.empty((Tout, self.K), dtype=self.dtype)
         self._check(self._lib.hscmp_convolve1d(self._h, _ptr(x2), T, 1 if same else 0, _ptr(out)), 'hscmp_convolve1d')
         return out
+
+    def assign_windows(self, windows):
+        """modeling.py:454-460: per window [L,F] of `windows` [N,L(,F)] the (position, atom, coefficient) of the
+        largest |valid correlation| with the dictionary, ties in C order."""
+        w3 = np.ascontiguousarray(windows.reshape((windows.shape[0], windows.shape[1], -1)), dtype=self.dtype)
+        assert w3.shape[2] == self.F
+        N, L = w3.shape[0], w3.shape[1]
+        t = np.empty((N,), dtype=np.int32); k = np.empty((N,), dtype=np.int32); c = np.empty((N,), dtype=self.dtype)
+        self._check(self._lib.hscmp_assign_windows(self._h, _ptr(w3), N, L, _ptr(t), _ptr(k), _ptr(c)), 'hscmp_assign_windows')
+        return t, k, c
 
     def select_best_atoms(self, innerProducts, filterWidth, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
         """modeling.py:899-982 on a materialised table [T,K]; returns (t, k, c) in the reference's order."""

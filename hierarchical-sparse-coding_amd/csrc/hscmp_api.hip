@@ -746,6 +746,46 @@ extern "C" int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, 
     return ctx->dtype == HSCMP_F32 ? run_convolve<float>(ctx, x, T, same, out) : run_convolve<double>(ctx, x, T, same, out);
 }
 
+// modeling.py:454-460: per-window best (position, atom, coefficient) of the k-means learner
+template <typename R>
+static int run_assign(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t* out_t, int32_t* out_k, void* out_c)
+{
+    const int K = ctx->K, W = ctx->W, F = ctx->F;
+    const size_t wbytes = (size_t)N * L * F * sizeof(R);
+    R* dwin = nullptr; int* dt = nullptr; int* dk = nullptr; R* dc = nullptr;
+    hipError_t e = hipSuccess;
+    int rc = HSCMP_OK;
+    do {
+        if ((e = hipMalloc((void**)&dwin, wbytes)) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&dt, (size_t)N * sizeof(int))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&dk, (size_t)N * sizeof(int))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&dc, (size_t)N * sizeof(R))) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(dwin, windows, wbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        const int lds_elems = (size_t)L * F * sizeof(R) <= 32768 ? L * F : 0;
+        hipLaunchKernelGGL((assign_windows_kernel<R>), dim3(N), dim3(kThreads), (size_t)lds_elems * sizeof(R), ctx->stream,
+                           (const R*)dwin, L, K, W, F, (const R*)ctx->d_D, lds_elems, dt, dk, dc);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out_t, dt, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out_k, dk, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if (out_c && (e = hipMemcpyAsync(out_c, dc, (size_t)N * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_assign_windows: %s", hipGetErrorString(e));
+    (void)hipFree(dwin); (void)hipFree(dt); (void)hipFree(dk); (void)hipFree(dc);
+    return rc;
+}
+
+extern "C" int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t* out_t, int32_t* out_k, void* out_c)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_assign_windows: ctx is NULL");
+    if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_assign_windows: no dictionary set");
+    if (!windows || !out_t || !out_k || N <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_assign_windows: bad arguments");
+    if (L < ctx->W) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_assign_windows: windows of %d samples are shorter than the filters (W=%d)", L, ctx->W);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ctx->dtype == HSCMP_F32 ? run_assign<float>(ctx, windows, N, L, out_t, out_k, out_c)
+                                   : run_assign<double>(ctx, windows, N, L, out_t, out_k, out_c);
+}
+
 #ifdef HSCMP_DBG_STAMPS
 extern "C" int hscmp_debug_blocks(unsigned long long* out, int n)
 {

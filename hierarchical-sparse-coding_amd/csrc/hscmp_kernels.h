@@ -88,6 +88,56 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
     }
 }
 
+// Window assignment of the convolutional k-means learner (modeling.py:454-460): for each of N windows
+// [L][F] the 'valid' correlation with every atom (Tout = L-W+1 positions) and the flat arg-max of |c|
+// over (position, atom) in C order (ties: lowest position, then lowest atom).
+//   grid = N, block = kThreads; the window is staged in LDS when it fits `lds_elems` elements
+template <typename R>
+__global__ __launch_bounds__(kThreads) void assign_windows_kernel(const R* __restrict__ windows, int L, int K, int W, int F,
+                                                                  const R* __restrict__ D, int lds_elems,
+                                                                  int* __restrict__ out_t, int* __restrict__ out_k, R* __restrict__ out_c)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* win = reinterpret_cast<R*>(smem);
+    __shared__ R red_c[kThreads];
+    __shared__ int red_o[kThreads];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const R* x = windows + (int64_t)n * L * F;
+    const bool staged = L * F <= lds_elems;
+    if (staged) {
+        for (int i = tid; i < L * F; i += kThreads) win[i] = x[i];
+        __syncthreads();
+    }
+    const R* src = staged ? win : x;
+    const int Tout = L - W + 1;
+    R bs = (R)-1, bc = (R)0;
+    int bo = INT_MAX;
+    for (int o = tid; o < Tout * K; o += kThreads) {           // ascending o per thread: '>' keeps the first of equals
+        const int t = o / K, k = o - t * K;
+        const R* dk = D + (int64_t)k * W * F;
+        R acc = (R)0;
+        for (int f = 0; f < F; ++f)
+            for (int w = 0; w < W; ++w) acc = rfma(src[(t + w) * F + f], dk[w * F + f], acc);    // pinned chain: f outer, w inner
+        const R sc = rabs(acc);
+        if (sc > bs) { bs = sc; bc = acc; bo = o; }
+    }
+    red_c[tid] = bc; red_o[tid] = bo;
+    __syncthreads();
+    for (int stride = kThreads / 2; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            const R ca = red_c[tid], cb = red_c[tid + stride];
+            const int oa = red_o[tid], ob = red_o[tid + stride];
+            const bool take = ob != INT_MAX && (oa == INT_MAX || rabs(cb) > rabs(ca) || (rabs(cb) == rabs(ca) && ob < oa));
+            if (take) { red_c[tid] = cb; red_o[tid] = ob; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int o = red_o[0] == INT_MAX ? 0 : red_o[0];       // all-NaN window: numpy's argmax returns the first NaN; not reproduced
+        out_t[n] = o / K; out_k[n] = o - (o / K) * K; out_c[n] = red_c[0];
+    }
+}
+
 // dense next-level input from the previous level's coefficient slots (modeling.py:1489 `todense()` of the
 // CSC matrix built by :1171-1181): x[b][t][k] = slot_a unless it is zero or below min_coefficients.
 //   grid = count, block = kThreads; x [count][T][F] must be zero filled

@@ -346,4 +346,7 @@ def __getattr__(name):
     if name == 'LoCOMP':
         from . import locomp
         return locomp.LoCOMP
+    if name in ('ConvolutionalDictionaryLearner', 'extractRandomWindows', 'extractWindows', 'extractWindowsBatch'):
+        from . import learning
+        return getattr(learning, name)
     raise AttributeError('module %r has no attribute %r' % (__name__, name))

@@ -135,6 +135,13 @@ int hscmp_encode_batch_device(hscmp_ctx* ctx, const void* x_dev, int B, int T, c
 int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, int first, int count, double min_coefficients,
                                   const hscmp_params* params);
 
+/* Window assignment of the convolutional k-means dictionary learner (ConvolutionalDictionaryLearner.
+ * _train_kmean, modeling.py:454-460 = convolve1d_batch(windows, D, 'valid') + arg-max of |c| per window):
+ * windows [N][L][F] in the dictionary's dtype (host), L >= W.  For every window the flat arg-max over
+ * (position 0..L-W, atom) in C order: out_t[n] position, out_k[n] atom, out_c[n] its coefficient (dtype;
+ * may be NULL). */
+int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t* out_t, int32_t* out_k, void* out_c);
+
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
  * between rounds.  max_rounds <= 0: until converged. */

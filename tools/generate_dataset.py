@@ -33,7 +33,8 @@ def signals(mld, nbSignals, nbSamples, rate=5e-4, compression=0.25, seed=5):
     for b in range(nbSignals):
         rs = np.random.RandomState((0x48534300 + seed) * 1000003 % (2 ** 31) + b)
         gen = SignalGenerator(mld, rate * np.ones(mld.getNbLevels()), rng=rs)
-        events, rates = gen.generateEvents(nbSamples, compression)
+        res = gen.generateEvents(nbSamples, compression)
+        events, rates = res if compression is not None else (res, gen.rates)
         xs.append(gen.generateSignalFromEvents(events, nbSamples=nbSamples))
         evs.append(events)
     return np.stack(xs), evs, rates

@@ -16,6 +16,8 @@ Files written:
   tests/golden/synth_small.npz  -- dataset synthesis (hsc/dataset.py:412-796) under fixed numpy seeds: generated
                                    multilevel dictionaries (raw, representations, decompositions), Poisson
                                    events with / without rate scaling, rendered signals
+  tests/golden/learn_small.npz  -- convolutional k-means dictionary learner (modeling.py:420-524) under fixed seeds and
+                                   its window-assignment step (convolve1d_batch + arg-max) on fixed windows
   tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
                                    singleton bases, representations, per-level coefficients, residual
 """
@@ -348,7 +350,7 @@ def gen_locomp():
 
 
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from golden_util import SYNTH_CASES  # noqa: E402  (the case table is shared with tests/test_dataset_synthesis.py)
+from golden_util import SYNTH_CASES, LEARN_CASES, learn_signal  # noqa: E402  (case tables shared with the tests)
 
 
 def gen_synth():
@@ -386,6 +388,38 @@ def gen_synth():
     print('wrote', path, os.path.getsize(path), 'bytes')
 
 
+def gen_learn():
+    """Convolutional k-means learner of the REAL reference (modeling.py:420-524) under fixed seeds, plus the
+    window-assignment step on its own (convolve1d_batch + arg-max, :454-460)."""
+    ref = load_reference()
+    out = {'names': np.array(sorted(LEARN_CASES))}
+    for name, (sig, k, w, seed, kw) in sorted(LEARN_CASES.items()):
+        data = learn_signal(sig)
+        np.random.seed(seed)
+        out[name + '__D'] = ref.modeling.ConvolutionalDictionaryLearner(k, w, algorithm='kmean').train(data, **kw)
+        # one assignment step on fixed windows / dictionary
+        rs = np.random.RandomState(seed + 100)
+        idx = rs.randint(0, data.shape[0] - 2 * w, size=64)
+        windows = ref.modeling.extractWindows(data, idx, 2 * w)
+        D0 = out[name + '__D']
+        ip = ref.modeling.convolve1d_batch(windows, D0, padding='valid')
+        flat = np.argmax(np.abs(ip.reshape(ip.shape[0], -1)), axis=1)
+        t, kk = np.unravel_index(flat, (ip.shape[1], ip.shape[2]))
+        out[name + '__win_idx'] = idx
+        out[name + '__assign_t'] = t.astype(np.int64); out[name + '__assign_k'] = kk.astype(np.int64)
+        out[name + '__assign_c'] = ip[np.arange(len(idx)), t, kk]
+        print('learn', name, out[name + '__D'].shape, out[name + '__D'].dtype)
+    # K-SVD on top of the matching pursuit (modeling.py:526-641); atoms are defined up to sign (SVD)
+    np.random.seed(3)
+    out['ksvd_1d__D'] = ref.modeling.ConvolutionalDictionaryLearner(6, 16, algorithm='ksvd').train(
+        learn_signal('planted_1d'), method='cmp', maxIterations=2, nbNonzeroCoefs=100, toleranceSnr=None)
+    np.random.seed(7)
+    out['samples_2d__D'] = ref.modeling.ConvolutionalDictionaryLearner(5, 9, algorithm='samples').train(learn_signal('sparse_2d'), avoidSingletons=True)
+    path = os.path.join(OUT, 'learn_small.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def scipy_sparse(c):
     import scipy.sparse
     return c if scipy.sparse.issparse(c) else scipy.sparse.csc_matrix(c)
@@ -394,7 +428,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp', 'synth']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp', 'synth', 'learn']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -407,3 +441,5 @@ if __name__ == '__main__':
         gen_locomp()
     if 'synth' in which:
         gen_synth()
+    if 'learn' in which:
+        gen_learn()
