@@ -365,14 +365,19 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
 static bool use_sparse_loop(const hscmp_ctx* ctx)
 {
     if (getenv("HSCMP_FORCE_DENSE")) return false;
-    // multi-feature inputs only (measured: for dense single-feature windows the dense chain is 3x faster)
+    // multi-feature inputs only (measured: for dense single-feature windows the dense chain is 3x faster), and
+    // only with a sparse dictionary: subtracting dense atoms fills the residual, the windows then overflow the
+    // gathered lists and the dense LDS-staged chain of GenericRecorr is several times faster (a k-means
+    // dictionary with ~150 of 528 non-zeros per atom: 1.3 ms vs 0.37 ms per atom)
+    if (ctx->d_nzptr == nullptr && !getenv("HSCMP_FORCE_GATHERED")) return false;
     return ctx->F > 1 && ctx->d_Dt != nullptr && ctx->W <= 16384 && ctx->F <= 32767;   // (f << 16) | row key
 }
 // Sparse INITIAL correlation: only for multi-feature inputs (hierarchical levels >= 1, almost all
 // zero); a dense single-feature signal is cheaper through the dense generic kernel.
 static bool use_sparse_init(const hscmp_ctx* ctx, int T)
 {
-    return use_sparse_loop(ctx) && ctx->F > 1 && T <= 262144;
+    if (getenv("HSCMP_FORCE_DENSE")) return false;
+    return ctx->F > 1 && ctx->d_Dt != nullptr && ctx->W <= 16384 && ctx->F <= 32767 && T <= 262144;
 }
 
 template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)

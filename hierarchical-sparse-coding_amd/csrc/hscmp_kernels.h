@@ -422,7 +422,7 @@ template <typename R> struct GenericRecorr {
             for (int i = tid; i < span * F; i += kThreads) {
                 const int jj = i / F, ff = i - jj * F;
                 const int gi = interior ? tstart + jj : reflect_index(tstart + jj, sidx, nslice);
-                win[i] = G.r[(int64_t)gi * F + ff];
+                win[ff * span + jj] = G.r[(int64_t)gi * F + ff];     // feature-major: lanes (consecutive rows) read consecutive words
             }
             __syncthreads();
         }
@@ -440,14 +440,15 @@ template <typename R> struct GenericRecorr {
             int bk = 0;
             if (rowok && g < ngrp) {
                 const int k0 = (int)(((int64_t)K * g) / ngrp), k1 = (int)(((int64_t)K * (g + 1)) / ngrp);
-                for (int k = k0; k < k1; ++k) {
+                int k = k0;
+                for (; k < k1; ++k) {
                     const R* dk = D + (int64_t)k * W * F;
                     R acc = (R)0;
                     if (staged) {
-                        const R* wj = win + (int64_t)j * F;          // row j's window starts at span row j
+                        const R* wj = win + j;                       // row j's window starts at span row j
                         for (int f = 0; f < F; ++f) {
 #pragma unroll 8
-                            for (int w = 0; w < W; ++w) acc = rfma(wj[w * F + f], dk[w * F + f], acc);
+                            for (int w = 0; w < W; ++w) acc = rfma(wj[f * span + w], dk[w * F + f], acc);
                         }
                     } else {
                         for (int f = 0; f < F; ++f)

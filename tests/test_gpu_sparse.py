@@ -8,7 +8,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {'paired': {}, 'atom_lists': {'HSCMP_NO_PAIRING': '1'}, 'gathered': {'HSCMP_NO_DICT_LISTS': '1'},
+VARIANTS = {'paired': {}, 'atom_lists': {'HSCMP_NO_PAIRING': '1'},
+            'gathered': {'HSCMP_NO_DICT_LISTS': '1', 'HSCMP_FORCE_GATHERED': '1'},
+            'dense_dictionary': {'HSCMP_NO_DICT_LISTS': '1'},        # sparse initial correlation + dense LDS-staged loop
             'paired_row_scan': {'HSCMP_NO_ROW_LISTS': '1'},
             'paired_no_rowbits': {'HSCMP_NO_ROW_LISTS': '1', 'HSCMP_NO_ROWBITS': '1'}}
 
@@ -101,12 +103,14 @@ def test_variants_are_the_ones_dispatched(monkeypatch):
     assert names['paired'].startswith('dictlist_init+dictlist_loop')
     assert names['atom_lists'].startswith('dictlist_init+dictlist_loop')
     assert names['gathered'].startswith('sparse_init+gathered_loop')
+    assert names['dense_dictionary'].startswith('sparse_init+generic_loop')
     assert names['paired_no_rowbits'].startswith('dictlist_init+dictlist_loop')
     assert names['paired_row_scan'].startswith('dictlist_init+dictlist_loop')
 
 
-def test_dense_level_dictionary_keeps_the_gathered_path():
-    """A dictionary with more than 32 non-zeros per atom gets no lists."""
+def test_dense_level_dictionary_takes_the_dense_loop():
+    """A dictionary with more than 32 non-zeros per atom gets no lists: its atoms fill the residual, so the
+    loop runs the dense LDS-staged chain (the input itself is still sparse: sparse initial correlation)."""
     from hsc_amd.modeling import ConvolutionalMatchingPursuit
     from oracle import hsc_oracle as orc
     rs = np.random.RandomState(3)
@@ -115,7 +119,7 @@ def test_dense_level_dictionary_keeps_the_gathered_path():
     D /= np.sqrt(np.sum(np.square(D), axis=(1, 2), keepdims=True))
     cmp = ConvolutionalMatchingPursuit()
     coefficients, residual = cmp.computeCoefficients(x, D, nbNonzeroCoefs=30)
-    assert cmp.lastResult.variant.startswith('sparse_init+gathered_loop')
+    assert cmp.lastResult.variant.startswith('sparse_init+generic_loop')
     coef, res, info = orc.cmp_encode(x, D, nbNonzeroCoefs=30)
     t, k, c = cmp.lastResult.events[0]
     assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c'])
