@@ -430,11 +430,19 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
     return HSCMP_OK;
 }
 
-template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, const void* x_dev)
+// Slots of the previous level an input was scattered from (level chaining): the input then already sits in the
+// residual buffer and prepare only needs the energy.
+struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; };
+
+template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, const void* x_dev, const ChainSource* chain = nullptr)
 {
     State<R> S = make_state<R>(ctx);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
+    if (chain)
+        hipLaunchKernelGGL((prepare_from_slots_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, chain->slot_t, chain->slot_k,
+                           chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc);
+    else
+        hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     bool mf = false;
     if (use_mfma(ctx, P.T)) {
@@ -521,9 +529,9 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     DevParams P;
     int rc = make_params(ctx, count, T, params, &P);
     if (rc) return rc;
-    if ((rc = ensure_workspace(ctx, P, true))) return rc;
+    if ((rc = ensure_workspace(ctx, P, false))) return rc;        // no input buffer: the slots are scattered straight into the residual
     const size_t bytes = (size_t)count * T * ctx->F * sizeof(double);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_x, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_resid, 0, bytes, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_rowflag, 0, (size_t)count * T, ctx->stream));
     const bool lists = use_sparse_loop(ctx) && use_row_lists(ctx);
     if (lists) {
@@ -531,13 +539,15 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_f, 0xff, (size_t)count * T * kRowListCap * sizeof(int), ctx->stream));
     }
     const int has_min = !std::isnan(min_coefficients);
-    hipLaunchKernelGGL((scatter_slots_kernel<double>), dim3(count), dim3(kThreads), 0, ctx->stream, (double*)ctx->d_x, T, ctx->F,
+    hipLaunchKernelGGL((scatter_slots_kernel<double>), dim3(count), dim3(kThreads), 0, ctx->stream, (double*)ctx->d_resid, T, ctx->F,
                        prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
                        has_min ? min_coefficients : 0.0, ctx->d_rowflag, lists ? ctx->d_rl_cnt : nullptr, ctx->d_rl_f, kRowListCap);
     ctx->P = P; ctx->last = *params; ctx->B = count; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
     ctx->rowflag_valid = true;                  // the sparse initial correlation skips its scan of the dense input
     ctx->rl_filled = lists;
-    rc = run_encode<double>(ctx, P, ctx->d_x);
+    const ChainSource chain{prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
+                            has_min ? min_coefficients : 0.0};
+    rc = run_encode<double>(ctx, P, ctx->d_resid, &chain);
     ctx->rowflag_valid = false; ctx->rl_filled = false;
     if (rc) return rc;
     ctx->have_batch = true;
@@ -789,6 +799,33 @@ extern "C" int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ctx->dtype == HSCMP_F32 ? run_assign<float>(ctx, windows, N, L, out_t, out_k, out_c)
                                    : run_assign<double>(ctx, windows, N, L, out_t, out_k, out_c);
+}
+
+// ---- host-side synthesis (modeling.py:226-263 reconstructSignal, sparse branch) ------------------------------
+// signal[t - (W-1)/2 + w][f] += c * D[k][w][f] for every event (t, k, c), in the order given, clipped at the borders
+// (utils.py:103-131): the reference's sequential overlap-add, float64 accumulation.  Plain host code (no GPU work):
+// it is the epilogue of the hierarchical encoder (modeling.py:1596-1611) and releases the Python interpreter lock
+// while it runs, so a batch can be post-processed on all cores.
+extern "C" int hscmp_host_overlap_add(double* signal, int64_t T, int Fd, const int64_t* rows, const int64_t* cols, const double* data,
+                                      int64_t n, const void* D, int W, int dict_is_f32)
+{
+    if (!signal || !D || (n > 0 && (!rows || !cols || !data)) || T <= 0 || Fd <= 0 || W <= 0) return HSCMP_ERR_INVALID;
+    const int64_t lead = (W - 1) / 2, atom = (int64_t)W * Fd;
+    for (int64_t i = 0; i < n; ++i) {
+        const double c = data[i];
+        if (c == 0.0) continue;
+        const int64_t p0 = rows[i] - lead;
+        const int64_t w0 = p0 < 0 ? -p0 : 0, w1 = p0 + W > T ? T - p0 : W;
+        double* dst = signal + (p0 + w0) * Fd;
+        if (dict_is_f32) {
+            const float* src = (const float*)D + cols[i] * atom + w0 * Fd;
+            for (int64_t e = 0; e < (w1 - w0) * Fd; ++e) dst[e] += c * (double)src[e];
+        } else {
+            const double* src = (const double*)D + cols[i] * atom + w0 * Fd;
+            for (int64_t e = 0; e < (w1 - w0) * Fd; ++e) dst[e] += c * src[e];
+        }
+    }
+    return HSCMP_OK;
 }
 
 #ifdef HSCMP_DBG_STAMPS

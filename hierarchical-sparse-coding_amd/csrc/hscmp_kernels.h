@@ -49,6 +49,60 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(DevParams P, State<R>
     }
 }
 
+// prepare for an input that was scattered from the previous level's coefficient slots straight into the
+// (zero-filled) residual: the signal energy comes from the slots.  The pinned energy order is 256 strided
+// partial sums, each sequential in the cell index i = t*F + f; a zero cell adds +0 and changes nothing, so
+// partial (i mod 256) only needs its non-zero cells in ascending i.  Every thread collects its cells from the
+// slot list and insertion-sorts them; if some partial has more cells than fit, the dense pass runs instead.
+//   grid = count, block = kThreads
+template <typename R>
+__global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams P, State<R> S, const int* __restrict__ slot_t,
+                                                                      const int* __restrict__ slot_k, const double* __restrict__ slot_a,
+                                                                      const int* __restrict__ pstats, int pcap, int first, int has_min,
+                                                                      double minc)
+{
+    __shared__ R red[2 * kWaves];
+    __shared__ int overflow;
+    constexpr int kLocal = 96;
+    const int b = blockIdx.x, tid = threadIdx.x, src = first + b;
+    const int n = pstats[(int64_t)src * ST_COUNT + ST_SLOTS];
+    long long cell[kLocal];
+    R val[kLocal];
+    int cnt = 0;
+    bool over = false;
+    if (tid == 0) overflow = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {                   // (all threads read the same entries: broadcast loads)
+        const double a = slot_a[(int64_t)src * pcap + i];
+        if (a == 0.0 || (has_min && !(fabs(a) >= minc))) continue;
+        const long long c = (long long)slot_t[(int64_t)src * pcap + i] * P.F + slot_k[(int64_t)src * pcap + i];
+        if ((int)(c & (kThreads - 1)) != tid) continue;
+        if (cnt == kLocal) { over = true; continue; }
+        int j = cnt++;
+        while (j > 0 && cell[j - 1] > c) { cell[j] = cell[j - 1]; val[j] = val[j - 1]; --j; }
+        cell[j] = c; val[j] = (R)a;
+    }
+    if (over) atomicOr(&overflow, 1);
+    __syncthreads();
+    R p = (R)0, q = (R)0;
+    if (overflow) {
+        const int64_t total = (int64_t)P.T * P.F;
+        const R* r = S.residual + (int64_t)b * total;
+        for (int64_t i = tid; i < total; i += kThreads) { const R v = r[i]; const R sq = v * v; p = p + sq; }
+    } else {
+        for (int j = 0; j < cnt; ++j) { const R sq = val[j] * val[j]; p = p + sq; }
+    }
+    pinned_tree2(p, q, red);
+    if (tid == 0) {
+        S.energy[2 * b + 0] = p;
+        S.energy[2 * b + 1] = p;
+        int* st = S.stats + (int64_t)b * ST_COUNT;
+        for (int i = 0; i < ST_COUNT; ++i) st[i] = 0;
+        S.edge[2 * b + 0] = 0ull;
+        S.edge[2 * b + 1] = 0ull;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic initial correlation: one thread per output position, all atoms, pinned fma chain
 //   grid = (ceil(Tout/kThreads), B), block = kThreads

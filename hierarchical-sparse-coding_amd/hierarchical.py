@@ -11,6 +11,7 @@ below) with the level's raw dictionary [K_l, W_l, K_{l-1}], singleton atoms down
 """
 import collections.abc
 import copy
+import os
 
 import numpy as np
 import scipy.sparse
@@ -218,7 +219,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
                     fmax = max(fmax, Dl.shape[2])
                     timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, chunks=0))
-                chunk = int(max(1, min(B, memoryBudget // (2.5 * T * fmax * 8 + 64 * T))))
+                # per signal on the device: the dense float64 residual [T, F] (the input is scattered straight into it) + per-row state
+                chunk = int(max(1, min(B, memoryBudget // (1.05 * T * fmax * 8 + 128 * T))))
                 for first in range(0, B if nbLevels > 1 else 0, chunk):
                     count = min(chunk, B - first)
                     for l in range(1, nbLevels):
@@ -232,12 +234,20 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                         acc = timings[l]
                         acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['chunks'] += 1
                         acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
-        coefficients, residuals = [], []
-        for b in range(B):
+        # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
+        # kernels it spends its time in release the interpreter lock
+        def finish(b):
             cb = self._postprocessCoefficients([per_level[l][b] for l in range(nbLevels)], multilevelDict, returnDistributed)
-            coefficients.append(cb)
-            residuals.append(self._calculateResidual(sequences[b], cb, multilevelDict))
-        return coefficients, np.stack(residuals, axis=0), timings
+            return cb, self._calculateResidual(sequences[b], cb, multilevelDict)
+        workers = max(1, min(16, os.cpu_count() or 1, B))
+        if workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                done = list(pool.map(finish, range(B)))
+        else:
+            done = [finish(b) for b in range(B)]
+        coefficients = [d[0] for d in done]
+        return coefficients, np.stack([d[1] for d in done], axis=0), timings
 
     def computeCoefficientsFromLevel(self, sequence, coefficients, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None,
                                      toleranceSnr=None, nbBlocks=1, minCoefficients=None, singletonWeight=0.5, stopCondition=None,

@@ -59,6 +59,22 @@ def convolve1d_batch(sequences, filters, padding='valid', device=0):
     return np.stack([eng.convolve1d(np.asarray(s, dtype=dt), same=(padding == 'same')) for s in seqs], axis=0)
 
 
+def _host_overlap_add(signal, rows, cols, data, D3):
+    """hscmp_host_overlap_add: the reference's event-by-event overlap-add in C (float64 signal and coefficients).
+    Returns False when the library is not available (the numpy formulation below gives the same result)."""
+    try:
+        lib = _native.load_library()
+    except Exception:
+        return False
+    Dc = np.ascontiguousarray(D3)
+    r = np.ascontiguousarray(rows, dtype=np.int64); c = np.ascontiguousarray(cols, dtype=np.int64)
+    v = np.ascontiguousarray(data, dtype=np.float64)
+    assert signal.flags['C_CONTIGUOUS']
+    rc = lib.hscmp_host_overlap_add(_native._ptr(signal), signal.shape[0], signal.shape[1], _native._ptr(r), _native._ptr(c),
+                                    _native._ptr(v), len(v), _native._ptr(Dc), Dc.shape[1], 1 if Dc.dtype == np.float32 else 0)
+    return rc == 0
+
+
 def reconstructSignal(coefficients, D):
     """hsc/modeling.py:226-263 -- synthesis: sum of c * D[k] centred at t over the non-zero
     coefficients [T,K] (sparse or dense).  Host-side overlap-add of the (few) events."""
@@ -76,7 +92,10 @@ def reconstructSignal(coefficients, D):
         data = dense[rows, cols]
     keep = data != 0.0
     rows, cols, data = rows[keep], cols[keep], data[keep]
-    if np.result_type(data.dtype, D3.dtype) != signal.dtype:
+    if signal.dtype == np.float64 and data.dtype == np.float64 and D3.dtype in (np.float32, np.float64) and len(data) > 0 \
+            and _host_overlap_add(signal, rows, cols, data, D3):
+        pass            # the sequential overlap-add ran in the native library (same sums, same order)
+    elif np.result_type(data.dtype, D3.dtype) != signal.dtype:
         # mixed precision: keep numpy's scalar-by-scalar casting of the reference loop
         for t, k, c in zip(rows, cols, data):
             overlapAdd(signal, c * D3[k], int(t), copy=False)

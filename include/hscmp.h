@@ -142,6 +142,14 @@ int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, int first, in
  * may be NULL). */
 int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t* out_t, int32_t* out_k, void* out_c);
 
+/* Host-side synthesis, the sparse branch of reconstructSignal (modeling.py:226-263, used by the residual of the
+ * hierarchical encoder, :1596-1611): for every event i in the order given, signal[rows[i] - (W-1)/2 + w][f] +=
+ * data[i] * D[cols[i]][w][f], clipped at the borders (utils.py:103-131).  signal float64 [T][Fd] (accumulated in
+ * place), D [K][W][Fd] float32 (dict_is_f32 != 0) or float64.  No GPU work and no context: plain host code that
+ * can run on many threads at once. */
+int hscmp_host_overlap_add(double* signal, int64_t T, int Fd, const int64_t* rows, const int64_t* cols, const double* data,
+                           int64_t n, const void* D, int W, int dict_is_f32);
+
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
  * between rounds.  max_rounds <= 0: until converged. */
