@@ -127,6 +127,12 @@ def nb_blocks_code(nbBlocks):
     return nb
 
 
+def max_event_capacity(T):
+    """Upper bound of the per-signal event lists: far beyond any converging pursuit (a signal of T samples is
+    explained by at most a few atoms per sample), small enough that a non-terminating one fails fast."""
+    return max(1 << 16, 16 * int(T))
+
+
 def make_params(nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None, nbBlocks=1,
                 minCoefficients=1e-16, eps=None, maxEvents=4096, maxRounds=0):
     nan = float('nan')

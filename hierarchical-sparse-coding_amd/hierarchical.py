@@ -177,6 +177,9 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 if not np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
                     break
                 maxEvents *= 4                       # enlarge the event lists and resume (exact, see hscmp_grow_events)
+                if maxEvents > _native.max_event_capacity(T):
+                    raise _native.HscmpError('the pursuit does not converge: more than %d selections per signal without meeting a '
+                                             'stop rule (the reference would not terminate)' % (maxEvents // 4))
                 eng.grow_events(maxEvents)
                 eng.continue_rounds(0)
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])

@@ -273,6 +273,9 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
             # the event list was too short for this stop rule: enlarge it and resume where the loop stopped
             # (a round is only started when all its atoms fit, so the trace equals an uninterrupted run)
             maxEvents *= 4
+            if maxEvents > _native.max_event_capacity(T):
+                raise _native.HscmpError('the pursuit does not converge: more than %d selections per signal without meeting a stop '
+                                         'rule (the same atoms are re-selected; the reference would not terminate)' % (maxEvents // 4))
             eng.grow_events(maxEvents)
             eng.continue_rounds(1 if per_round else 0)
             kernel_ms[2] += eng.last_kernel_ms()[2]

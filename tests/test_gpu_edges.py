@@ -1,0 +1,87 @@
+"""GPU parity (-m gpu) on degenerate inputs, against the CPU oracle: all-zero signals, single samples,
+single-tap / single-atom dictionaries, signals shorter than the filters, constant signals (ties everywhere),
+multi-feature inputs with a single feature row, batches mixing converged and running signals."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(x, D, **kw):
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from oracle import hsc_oracle as orc
+    cmp = ConvolutionalMatchingPursuit()
+    coefficients, residual = cmp.computeCoefficients(x, D, **kw)
+    coef, res, info = orc.cmp_encode(x, D, **kw)
+    t, k, c = cmp.lastResult.events[0]
+    assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), cmp.lastResult.variant
+    assert np.array_equal(residual, res)
+    assert residual.shape == res.shape and residual.dtype == res.dtype
+    assert (coefficients != coef).nnz == 0
+    assert cmp.lastResult.stop_reasons()[0] == info['stop']
+    return info
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_zero_signal_stops_before_the_first_selection(dtype):
+    rs = np.random.RandomState(0)
+    D = rs.standard_normal((8, 16)).astype(dtype)
+    info = _check(np.zeros(300, dtype=dtype), D, nbNonzeroCoefs=5)
+    assert len(info['t']) == 0
+    info = _check(np.zeros((300, 3), dtype=dtype), rs.standard_normal((4, 5, 3)).astype(dtype), toleranceSnr=10.0, nbBlocks=4)
+    assert len(info['t']) == 0
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('T,K,W', [(1, 3, 1), (2, 1, 1), (5, 4, 9), (9, 2, 9), (17, 1, 4), (64, 5, 1), (33, 3, 32)])
+def test_tiny_and_short_signals(T, K, W, dtype):
+    rs = np.random.RandomState(T * 100 + K * 10 + W)
+    D = rs.standard_normal((K, W)).astype(dtype)
+    D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
+    x = rs.standard_normal(T).astype(dtype)
+    _check(x, D, nbNonzeroCoefs=4)
+    if T >= 4:                                   # (a block size of 0 is an error in the reference as well)
+        _check(x, D, nbNonzeroCoefs=3, nbBlocks=2)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_constant_signal_ties_resolve_like_the_reference(dtype):
+    """Every interior position has the same score: the first position (then the first atom) must win."""
+    D = np.stack([np.ones(8), np.ones(8), -np.ones(8)]).astype(dtype) / np.sqrt(8)
+    x = np.ones(200, dtype=dtype)
+    info = _check(x, D, nbNonzeroCoefs=6)
+    assert info['k'][0] == 0
+    _check(x, D, nbNonzeroCoefs=12, nbBlocks='auto')
+
+
+def test_batch_with_signals_that_converge_at_different_times():
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from oracle import hsc_oracle as orc
+    rs = np.random.RandomState(5)
+    D = rs.standard_normal((16, 24)).astype(np.float32)
+    D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
+    xs = np.zeros((5, 1500), dtype=np.float32)
+    xs[1, 100:124] = 2.0 * D[3]                                  # one atom: converges at once
+    xs[2] = rs.standard_normal(1500)                             # noise: runs into the L0 limit
+    xs[3, 700:724] = D[5]; xs[3, 705:729] -= 0.5 * D[7]
+    xs[4] = 1e-30                                                # tiny: below eps right away
+    cmp = ConvolutionalMatchingPursuit()
+    res = cmp.computeCoefficientsBatch(xs, D, nbNonzeroCoefs=40, toleranceSnr=30.0)
+    for b in range(5):
+        coef, r, info = orc.cmp_encode(xs[b], D, nbNonzeroCoefs=40, toleranceSnr=30.0)
+        t, k, c = res.events[b]
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), b
+        assert np.array_equal(res.residuals[b], r)
+        assert res.stop_reasons()[b] == info['stop']
+
+
+def test_non_converging_pursuit_raises_instead_of_growing_forever():
+    """Two identical feature planes of a constant signal: after the first atom the reference's reflect-padded
+    re-correlation (modeling.py:1046) keeps re-selecting position 0 with the same coefficient, nnz never
+    grows and the reference loops forever.  The engine enlarges its event lists up to a bound, then raises."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from hsc_amd._native import HscmpError
+    D = np.stack([np.ones(8), np.ones(8), -np.ones(8)]) / np.sqrt(8)
+    x = np.ones((200, 2))
+    with pytest.raises(HscmpError, match='does not converge'):
+        ConvolutionalMatchingPursuit().computeCoefficients(x, np.stack([D, D], axis=2), nbNonzeroCoefs=6)
