@@ -843,8 +843,8 @@ extern "C" int hscmp_debug_counters(unsigned long long* out16, int reset)
 
 extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
 {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hscmp::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hscmp::g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hscmp::g_stamps), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;      // (64 entries)
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hscmp::g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

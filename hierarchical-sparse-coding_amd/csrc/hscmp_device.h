@@ -15,17 +15,17 @@ namespace hscmp {
 
 #ifdef HSCMP_DBG_STAMPS
 // diagnostic build only (tools/read_stamps.py); never compiled into the product library
-__device__ unsigned long long g_stamps[16];      // per-phase cycle sums of workgroup 0
+__device__ unsigned long long g_stamps[64];      // per-phase cycle sums of workgroup 0: [0,16) fused atom body, [32,48) step-by-step body and sparse_rows
 __device__ unsigned long long g_blk[3 * 4096];   // per workgroup: start, end (100 MHz wall clock), XCC/HW id
 __device__ unsigned long long g_cnt[16];         // free-form event counters of workgroup 0
 #endif
 #ifdef HSCMP_DBG_STAMPS
 // diagnostic build only: per-phase cycle sums of workgroup 0 (thread 0), read back by
 // tools/read_stamps.py / tools/hsc_stamps.py through hscmp_debug_stamps(); never compiled into the product library
-#define HSCMP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_stamps[i] += now_ - stamp_last_; stamp_last_ = now_; } } while (0)
+#define HSCMP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_stamps[i] += now_ - stamp_last_; stamp_last_ = now_; } } while (0)
 #define HSCMP_STAMP_BEGIN() unsigned long long stamp_last_ = clock64()
 #define HSCMP_COUNT(i) (g_stamps[i] += 1)
-#define HSCMP_TALLY(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cnt[i] += (unsigned long long)(v); } while (0)
+#define HSCMP_TALLY(i, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cnt[i] += (unsigned long long)(v); } while (0)
 #else
 #define HSCMP_STAMP(i) do {} while (0)
 #define HSCMP_STAMP_BEGIN() do {} while (0)

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         int nsel;
-        if constexpr (!Recorr::kFused) HSCMP_STAMP(7);
+        if constexpr (!Recorr::kFused) HSCMP_STAMP(39);
         // =========================== select (modeling.py:899-982) ===========================
         int p_sel = 0, k_sel = 0;
         R c_sel = (R)0;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
             return;
         }
-        if constexpr (!Recorr::kFused) HSCMP_STAMP(0);
+        if constexpr (!Recorr::kFused) HSCMP_STAMP(32);
         // A round whose atoms do not all fit the event list is not started: the state then is exactly that
         // of a round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
         const bool lists_full = sh.nev + nsel > P.cap;  // uniform (LDS values after a barrier)
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             // above, and the next read comes after the barriers of the residual update
             if (new_slot) sh.bloom[hb >> 5] |= 1u << (hb & 31);
             if (sh.skip) break;
-            if constexpr (!Recorr::kFused) HSCMP_STAMP(1);
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(33);
 
             // ---- :1117, :996-1016 residual subtract with local energy before / after
             int s, e, es;
@@ -822,11 +822,11 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
             }
 
-            if constexpr (!Recorr::kFused) HSCMP_STAMP(2);
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(34);
             // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
             Recorr::run(P, S, G, sh, A, plds, p, k);
             __syncthreads();
-            if constexpr (!Recorr::kFused) HSCMP_STAMP(3);
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(35);
 
             // ---- refresh the maxima of the touched segments
             {
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 }
             }
             __syncthreads();
-            if constexpr (!Recorr::kFused) { HSCMP_STAMP(4); if (blockIdx.x == 0 && tid == 0) HSCMP_COUNT(14); }
+            if constexpr (!Recorr::kFused) { HSCMP_STAMP(36); if (blockIdx.x == 0 && tid == 0) HSCMP_COUNT(46); }
             if (sh.converged) break;
         }
 

@@ -312,7 +312,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
     // ---- 1. the non-zeros of the window (any order)
     HSCMP_STAMP_BEGIN();
     const int n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
-    HSCMP_STAMP(8);
+    HSCMP_STAMP(40);
     HSCMP_TALLY(0, 1); HSCMP_TALLY(1, n); HSCMP_TALLY(2, n > nzcap); HSCMP_TALLY(5, L.ctl[1]);
 
     if (A.fptr && n <= nzcap) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
         }
         __syncthreads();
         const int m = L.ctl[2];
-        HSCMP_STAMP(9);
+        HSCMP_STAMP(41);
         HSCMP_TALLY(3, m); HSCMP_TALLY(4, m > reccap);
         if (m <= reccap) {
             //  b. sort by (output, chain order); the keys are distinct.  Few output rows: bucket by row first
@@ -386,7 +386,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 }
             }
             __syncthreads();
-            HSCMP_STAMP(10);
+            HSCMP_STAMP(42);
             //  c. one chain per output, run by the thread of its first record (f outer, w inner from +0)
             for (int sp = tid; sp < m; sp += kThreads) {
                 const unsigned ok = (unsigned)(L.rkey[L.perm[sp]] >> 32);
@@ -404,7 +404,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 L.okey[sp] = mark;
             }
             __syncthreads();
-            HSCMP_STAMP(11);
+            HSCMP_STAMP(43);
             //  d. per-row best over atoms, one thread per row: the listed outputs (ascending k inside a row) against
             //     the zeros of all the others -- a zero score never beats k = 0, the first of the ties
             for (int row = tid; row < nrows; row += kThreads) {
@@ -425,7 +425,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 G.bc[t] = c; G.bk[t] = k;
             }
             __syncthreads();
-            HSCMP_STAMP(12);
+            HSCMP_STAMP(44);
             return;
         }
     }
@@ -540,6 +540,7 @@ template <typename R> struct SparseRecorr {
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
                                                char* lds, int p, int k)
     {
+        HSCMP_STAMP_BEGIN();
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
         const int T = P.T, W = P.W;
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
@@ -554,9 +555,17 @@ template <typename R> struct SparseRecorr {
             for (int e = e0 + (int)threadIdx.x; e < e1; e += kThreads) {
                 const int wf = A.nzwf[e], f = wf & 0xffff, g = p - P.off + (wf >> 16);
                 if (g < 0 || g >= T) continue;                         // clipped part of the atom (utils.py:110-129)
+                // the whole list of the row in one go (empty slots hold -1 and never match); an overflowed row
+                // (count > C) is read densely anyway
                 const int n = list_count(cnt + g);
-                bool listed = n > C;                                    // an overflowed row is read densely anyway
-                for (int q = 0; q < min(n, C) && !listed; ++q) listed = lf[(int64_t)g * C + q] == f;
+                bool listed = n > C;
+                if (C == 8) {
+                    const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)g * 8);
+                    const int4 a = row[0], b = row[1];
+                    listed |= a.x == f || a.y == f || a.z == f || a.w == f || b.x == f || b.y == f || b.z == f || b.w == f;
+                } else {
+                    for (int q = 0; q < C; ++q) listed |= lf[(int64_t)g * C + q] == f;
+                }
                 if (!listed) {
                     const int o = atomicAdd(&cnt[g], 1);
                     if (o < C) lf[(int64_t)g * C + o] = f;
@@ -572,6 +581,7 @@ template <typename R> struct SparseRecorr {
         const int tend = p + W / 2 + (W - 1);              // :1038
         const int sidx = tstart < 0 ? 0 : tstart;          // :1034
         const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
+        HSCMP_STAMP(45);
         sparse_rows(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1);
     }
 };

@@ -38,24 +38,23 @@ if CONFIG5:
     mld = mld.withSingletonBases()
     snr = [30.0, 35.0, 35.0]
 lib = _native.load_library()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 64)()
 hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
 lib.hscmp_debug_stamps(out, 1)
 coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, toleranceSnr=snr, nbBlocks=blocks, singletonWeight=0.95)
 lib.hscmp_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
-n = max(v[14], 1)
+n = max(v[46], 1)
 for tm in timings:
     print('level %d: %-28s init %.2f ms  loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
-print('NOTE: indices 0-7 also receive the fused level-0 loop of workgroup 0 (small next to level 1)')
 names = ['select (per round)', 'bookkeeping', 'residual update', 're-correlation', 'segments + stop', '-', '-', 'slow stop rules (per round)']
 print('workgroup 0: %d atoms' % n)
 for i, nm in enumerate(names):
-    print('  %-28s %9.0f cycles/atom' % (nm, v[i] / n))
-print('  total %.0f cycles/atom' % (v[:8].sum() / n))
-sub = ['gather', 'pairing', 'sort', 'chains', 'row arg-max']
+    print('  %-28s %9.0f cycles/atom' % (nm, v[32 + i] / n))
+print('  total %.0f cycles/atom' % (v[32:40].sum() / n))
+sub = ['gather', 'pairing', 'sort', 'chains', 'row arg-max', 'list append (before the gather)']
 for i, nm in enumerate(sub):
-    print('    re-correlation / %-14s %9.0f cycles/atom' % (nm, v[8 + i] / n))
+    print('    re-correlation / %-14s %9.0f cycles/atom' % (nm, v[40 + i] / n))
 cnt = (ctypes.c_ulonglong * 16)()
 lib.hscmp_debug_counters(cnt, 1)
 c = np.array(list(cnt), dtype=np.float64)

@@ -11,7 +11,7 @@ x = torch.from_numpy(synth.make_batch(D, 65536, 0, 8, kind='planted', nb_atoms=2
 eng = _native.Engine(0); eng.set_dictionary(D)
 params = _native.make_params(nbNonzeroCoefs=256, eps=1.2e-7, maxEvents=576)
 lib = _native.load_library()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 64)()
 for i in range(3):
     eng.encode_batch_device(x.data_ptr(), B, 65536, params); eng.synchronize()
     lib.hscmp_debug_stamps(out, 1)
