@@ -45,3 +45,18 @@ try:
     print('first-round workgroups: %d on %d distinct CUs; per-CU histogram %s' % (int(first.sum()), len(cnt), dict(collections.Counter(cnt.values()))))
 except Exception as ex:
     print('no block info', ex)
+
+# which workgroups share a CU in the first residency round (diagnostic for priority experiments)
+try:
+    order = np.argsort(st)
+    first_idx = np.where(first)[0]
+    by_cu = collections.defaultdict(list)
+    for i in first_idx:
+        by_cu[int(key[i])].append(int(i))
+    pairs = [tuple(sorted(v)) for v in by_cu.values() if len(v) == 2]
+    diffs = collections.Counter([b - a for a, b in pairs])
+    print('pairs sharing a CU: %d; blockIdx difference histogram (top 8): %s' % (len(pairs), diffs.most_common(8)))
+    print('parity of (blockIdx >> 8) differs within a pair: %d of %d; parity of blockIdx differs: %d' % (
+        sum(((a >> 8) & 1) != ((b >> 8) & 1) for a, b in pairs), len(pairs), sum((a & 1) != (b & 1) for a, b in pairs)))
+except Exception as ex:
+    print('no pair info', ex)
