@@ -870,6 +870,7 @@ static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const
     }
     const int64_t nitems = (int64_t)((P.T + kMfmaChunk - 1) / kMfmaChunk) * P.B;
     int64_t grid = (int64_t)cus * per_cu;
+    if (const char* e = getenv("HSCMP_INIT_PER_CU")) grid = (int64_t)cus * std::max(1, atoi(e));      // diagnostic: fewer resident workgroups
     if (grid > nitems) grid = nitems;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), lds, stream, P, S, A);
     return 0;
