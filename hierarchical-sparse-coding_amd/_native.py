@@ -23,7 +23,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
            'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_encode_batch',
-           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_stop_signal', 'hscmp_fetch_events',
+           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
 
@@ -85,6 +85,7 @@ def load_library():
     lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
     lib.hscmp_continue.argtypes = [vp, ci]
     lib.hscmp_grow_events.argtypes = [vp, ci]
+    lib.hscmp_mem_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.hscmp_stop_signal.argtypes = [vp, ci]
     lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
     lib.hscmp_fetch_stats.argtypes = [vp, vp]
@@ -271,6 +272,12 @@ class Engine(object):
         """Larger event / slot lists, contents kept; signals stopped on capacity run again on continue_rounds()."""
         self._check(self._lib.hscmp_grow_events(self._h, int(max_events)), 'hscmp_grow_events')
         self._batch = (self._batch[0], self._batch[1], int(max_events))
+
+    def mem_info(self):
+        """(free, total) bytes of this engine's GPU."""
+        f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.hscmp_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)), 'hscmp_mem_info')
+        return int(f.value), int(t.value)
 
     def stop_signal(self, b):
         self._check(self._lib.hscmp_stop_signal(self._h, int(b)), 'hscmp_stop_signal')

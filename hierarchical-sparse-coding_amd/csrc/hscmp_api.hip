@@ -721,6 +721,16 @@ extern "C" int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4)
     return HSCMP_OK;
 }
 
+extern "C" int hscmp_mem_info(hscmp_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    if (!ctx || !free_bytes || !total_bytes) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_mem_info: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+    return HSCMP_OK;
+}
+
 extern "C" const char* hscmp_last_variant(hscmp_ctx* ctx) { return ctx ? ctx->variant.c_str() : ""; }
 
 // modeling.py:149-188 convolve1d on the GPU: full table out [Tout][K]

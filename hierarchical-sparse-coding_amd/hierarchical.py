@@ -142,12 +142,12 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             e.close()
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
-                                 returnDistributed=True, chained=True, memoryBudget=64e9):
+                                 returnDistributed=True, chained=True, memoryBudget=None):
         """Batch form (the reference has no batch axis): `sequences` [B,T] (or [B,T,F]); every level encodes
         many signals per GPU call.  chained=True keeps the level hand-off on the device
         (hscmp_encode_batch_from_level): the dense [T, K_prev] float64 input of a level (modeling.py:1489)
         is scattered from the previous level's coefficient slots in GPU memory, in chunks of signals
-        that fit `memoryBudget` bytes -- at BASELINE config 4 that input is 134 MB per signal and can
+        that fit `memoryBudget` bytes (default: 60 % of the GPU's memory) -- at BASELINE config 4 that input is 134 MB per signal and can
         not travel through the host.  chained=False builds the dense inputs on the host (small cases).
         Returns (per-signal lists of per-level coefficient matrices, residuals [B,T(,F)] float64,
         per-level kernel timings)."""
@@ -222,6 +222,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
                     fmax = max(fmax, Dl.shape[2])
                     timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, chunks=0))
+                if memoryBudget is None:
+                    memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
                 # per signal on the device: the dense float64 residual [T, F] (the input is scattered straight into it) + per-row state
                 chunk = int(max(1, min(B, memoryBudget // (1.05 * T * fmax * 8 + 128 * T))))
                 for first in range(0, B if nbLevels > 1 else 0, chunk):

@@ -195,6 +195,10 @@ int hscmp_get_device_view(hscmp_ctx* ctx, hscmp_device_view* view);
  * out[2] = greedy loop (modeling.py:1086-1163), out[3] = reserved. */
 int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4);
 
+/* Free / total memory of the context's GPU in bytes (hosts size their signal chunks with it: a level of the
+ * hierarchical encoder keeps a dense float64 residual [T][K_prev] per signal on the device). */
+int hscmp_mem_info(hscmp_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+
 /* Name of the kernel variant the last encode dispatched ("mfma_f32", "generic_f64", ...). */
 const char* hscmp_last_variant(hscmp_ctx* ctx);
 

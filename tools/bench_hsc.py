@@ -34,7 +34,7 @@ hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
 for rep in range(2):
     t0 = time.perf_counter()
     coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, toleranceSnr=[30.0, 40.0], nbBlocks=10, singletonWeight=0.95,
-                                                             memoryBudget=float(os.environ.get('MEM', '64e9')))
+                                                             memoryBudget=(float(os.environ['MEM']) if 'MEM' in os.environ else None))
     wall = time.perf_counter() - t0
 snr = 10 * np.log10(np.sum(xs.astype(np.float64) ** 2) / np.sum(residuals ** 2))
 print('B=%d T=%d L0 %dx%d, L1 (%d+%d)x%dx%d  wall %.2f s  SNR %.1f dB  nnz/level %s' % (
