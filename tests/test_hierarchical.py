@@ -159,3 +159,35 @@ def test_events_wire_format_matches_reference():
         row, col, data = gu.csc_triplets(b)
         assert np.array_equal(row, z['case_a__back%d_row' % l]) and np.array_equal(col, z['case_a__back%d_col' % l])
         assert np.array_equal(data.astype(np.float32), z['case_a__back%d_data' % l].astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['a', 'b'])
+def test_hierarchical_medium_generated_data_vs_reference(name):
+    """2-level encode of generated data (Perlin dictionary, Poisson events, 8192 samples; level-1 dictionary
+    (24+20) x 33 x 24, sparse x sparse kernels) against the coefficients of the REAL reference
+    (tests/golden/hsc_medium.npz, tools/make_golden.py hscmed): positions and atoms exact, values 1e-5."""
+    import hashlib
+    from hsc_amd.dataset import MultilevelDictionaryGenerator, SignalGenerator
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, HierarchicalConvolutionalSparseCoder
+    z = gu.load('hsc_medium.npz')
+    np.random.seed(77)
+    mld = MultilevelDictionaryGenerator().generate(scales=[32, 64], counts=[24, 20], decompositionSize=3,
+                                                   multilevelDecomposition=False, maxNbPatternsConsecutiveRejected=50)
+    np.random.seed(78)
+    gen = SignalGenerator(mld, [0.004, 0.004])
+    events = gen.generateEvents(8192)
+    x = gen.generateSignalFromEvents(events, nbSamples=8192)
+    assert len(events) == int(z['nevents'])
+    assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == str(z['x_sha256'])
+    kw = dict(a=dict(toleranceSnr=[20.0, 25.0], nbBlocks=8, singletonWeight=0.9),
+              b=dict(toleranceSnr=[25.0, 30.0], nbBlocks='auto', singletonWeight=0.95, returnDistributed=False))[name]
+    hcsc = HierarchicalConvolutionalSparseCoder(mld, HierarchicalConvolutionalMatchingPursuit(method='cmp'))
+    coefficients, residual = hcsc.encode(x, **kw)
+    for l, c in enumerate(coefficients):
+        row, col, data = gu.csc_triplets(scipy.sparse.csc_matrix(c))
+        assert np.array_equal(row, z['case_%s__level%d_row' % (name, l)]), l
+        assert np.array_equal(col, z['case_%s__level%d_col' % (name, l)]), l
+        assert gu.rel_err(data, z['case_%s__level%d_data' % (name, l)]) <= 1e-5
+    e = float(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
+    assert abs(e - float(z['case_%s__residual_energy' % name])) <= 1e-5 * float(z['case_%s__residual_energy' % name])

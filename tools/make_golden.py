@@ -18,6 +18,8 @@ Files written:
                                    events with / without rate scaling, rendered signals
   tests/golden/learn_small.npz  -- convolutional k-means dictionary learner (modeling.py:420-524) under fixed seeds and
                                    its window-assignment step (convolve1d_batch + arg-max) on fixed windows
+  tests/golden/hsc_medium.npz   -- 2-level hierarchical encoder on generated data (8192 samples, level-1 dictionary
+                                   (24+20) x 33 x 24): per-level coefficients of the reference, inputs by seed
   tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
                                    singleton bases, representations, per-level coefficients, residual
 """
@@ -301,6 +303,36 @@ def gen_hsc():
     print('hsc_small.npz: %d cases' % len(names))
 
 
+def gen_hsc_medium():
+    """Hierarchical encoder of the REAL reference on generated data at a realistic level-1 shape: Perlin
+    dictionary (scales [32, 64], 24 + 20 patterns), Poisson-event signal of 8192 samples, blocked selection.
+    The dictionary and the signal are regenerated by the tests from the seeds (tests/test_dataset_synthesis.py
+    pins the generators), only digests and the reference's coefficients are stored."""
+    import hashlib
+    ref = load_reference()
+    out = {}
+    np.random.seed(77)
+    mld = ref.dataset.MultilevelDictionaryGenerator().generate(scales=[32, 64], counts=[24, 20], decompositionSize=3,
+                                                               multilevelDecomposition=False, maxNbPatternsConsecutiveRejected=50)
+    np.random.seed(78)
+    gen = ref.dataset.SignalGenerator(mld, [0.004, 0.004])
+    events = gen.generateEvents(8192)
+    x = gen.generateSignalFromEvents(events, nbSamples=8192)
+    out['x_sha256'] = np.array(hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest())
+    out['nevents'] = np.int64(len(events))
+    for name, kw in (('a', dict(toleranceSnr=[20.0, 25.0], nbBlocks=8, singletonWeight=0.9)),
+                     ('b', dict(toleranceSnr=[25.0, 30.0], nbBlocks='auto', singletonWeight=0.95, returnDistributed=False))):
+        t0 = time.time()
+        hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mld, ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='cmp'))
+        coefficients, residual = hcsc.encode(x, **kw)
+        for l, c in enumerate(coefficients):
+            pack_csc('case_%s__level%d' % (name, l), scipy_sparse(c), out)
+        out['case_%s__residual_energy' % name] = np.float64(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
+        print('hsc_medium', name, [c.nnz for c in coefficients], '%.1f s' % (time.time() - t0))
+    np.savez_compressed(os.path.join(OUT, 'hsc_medium.npz'), **out)
+    print('wrote hsc_medium.npz', os.path.getsize(os.path.join(OUT, 'hsc_medium.npz')), 'bytes')
+
+
 def gen_locomp():
     """LoCOMP (modeling.py:1191-1425) on small seeded problems."""
     ref = load_reference()
@@ -428,7 +460,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'locomp', 'synth', 'learn']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'locomp', 'synth', 'learn']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -437,6 +469,8 @@ if __name__ == '__main__':
         gen_config()
     if 'hsc' in which:
         gen_hsc()
+    if 'hscmed' in which:
+        gen_hsc_medium()
     if 'locomp' in which:
         gen_locomp()
     if 'synth' in which:
