@@ -1,0 +1,102 @@
+"""Seeded random sweep (-m gpu) of shapes, dtypes, stop rules and selection modes through the single-signal
+entry point, bit for bit against the CPU oracle.  The shapes are drawn so that every dispatch path is hit:
+MFMA (F = 1, T >= 3W-2), generic (short signals, F > 1 with dense dictionaries), sparse multi-feature paths
+(sparse dictionaries with singletons)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 320
+
+
+def _draw(i):
+    rs = np.random.RandomState(9000 + i)
+    dtype = np.float32 if rs.rand() < 0.5 else np.float64
+    family = i % 4
+    if family == 0:                                           # single feature, MFMA-sized
+        W = int(rs.choice([3, 4, 7, 8, 16, 17, 31, 32, 40]))
+        K = int(rs.choice([1, 2, 5, 16, 31, 32, 33, 48, 70]))
+        T = int(rs.randint(3 * W, 40 * W + 50))
+        F = 1
+    elif family == 1:                                         # single feature, short / odd
+        W = int(rs.randint(1, 24)); K = int(rs.randint(1, 12)); T = int(rs.randint(max(2, W // 2), 3 * W + 4)); F = 1
+    elif family == 2:                                         # multi-feature, dense dictionary
+        W = int(rs.randint(2, 12)); K = int(rs.randint(1, 10)); T = int(rs.randint(2 * W, 30 * W)); F = int(rs.randint(2, 7))
+    else:                                                     # multi-feature, sparse dictionary + singletons
+        W = int(rs.randint(2, 20)); F = int(rs.randint(2, 40)); K = int(rs.randint(1, 16)); T = int(rs.randint(3 * W, 60 * W))
+    if family == 3:
+        D = np.zeros((K, W, F), dtype=dtype)
+        for k in range(K):
+            for _ in range(int(rs.randint(1, 5))):
+                D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+            D[k] /= np.sqrt(np.sum(np.square(D[k])))
+        S = np.zeros((F, W, F), dtype=dtype)
+        S[np.arange(F), (W - 1) // 2, np.arange(F)] = 1.0
+        D = np.concatenate((S, D), axis=0)
+        x = np.zeros((T, F), dtype=dtype)
+        for _ in range(max(1, T // 12)):
+            x[rs.randint(0, T), rs.randint(0, F)] = rs.uniform(0.3, 2.0) * rs.choice([-1.0, 1.0])
+    else:
+        shape = (K, W) if F == 1 else (K, W, F)
+        D = rs.standard_normal(shape).astype(dtype)
+        D /= np.sqrt(np.sum(np.square(D), axis=tuple(range(1, D.ndim)), keepdims=True))
+        x = rs.standard_normal((T,) if F == 1 else (T, F)).astype(dtype)
+        if rs.rand() < 0.5:                                   # planted structure on top of weak noise
+            x *= dtype(0.05)
+            D3 = D.reshape((K, W, -1)); x2 = x.reshape((T, -1))
+            for _ in range(max(1, T // (2 * W))):
+                k = rs.randint(0, K); t = rs.randint(0, max(1, T - W)); n = min(W, T - t)
+                x2[t:t + n] += (rs.uniform(0.5, 2.0) * D3[k][:n]).astype(dtype)
+    kw = {}
+    rule = rs.randint(0, 4)
+    if rule == 0:
+        kw['nbNonzeroCoefs'] = int(rs.randint(1, 40))
+    elif rule == 1:
+        kw['toleranceSnr'] = float(rs.uniform(3.0, 25.0)); kw['nbNonzeroCoefs'] = 60
+    elif rule == 2:
+        kw['toleranceResidualScale'] = float(rs.uniform(0.2, 1.0)) * float(np.max(np.abs(x))); kw['nbNonzeroCoefs'] = 60
+    else:
+        kw['nbNonzeroCoefs'] = int(rs.randint(1, 25)); kw['toleranceSnr'] = 30.0
+    mode = rs.randint(0, 3)
+    if mode == 1 and T >= 8:
+        kw['nbBlocks'] = int(rs.randint(2, min(9, T // 2)))
+    elif mode == 2:
+        kw['nbBlocks'] = 'auto'
+    if rs.rand() < 0.3:
+        w = rs.uniform(0.5, 1.0, size=D.shape[0]).astype(dtype)
+        kw['weights'] = w
+    if rs.rand() < 0.2:
+        kw['minCoefficients'] = None
+    return x, D, kw
+
+
+@pytest.mark.parametrize('i', range(N_CASES))
+def test_random_configuration_vs_oracle(i):
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from hsc_amd._native import HscmpError
+    from oracle import hsc_oracle as orc
+    x, D, kw = _draw(i)
+    okw = dict(kw)
+    coef, res, info = orc.cmp_encode(x, D, maxEvents=1 << 17, **okw)          # beyond the engine's own bound
+    if info['stop'] == 'capacity':
+        # a pursuit that does not converge under the drawn rule (the reference would not terminate either):
+        # the engine must say so instead of looping
+        with pytest.raises(HscmpError, match='does not converge'):
+            ConvolutionalMatchingPursuit().computeCoefficients(x, D, **kw)
+        return
+    cmp = ConvolutionalMatchingPursuit()
+    coefficients, residual = cmp.computeCoefficients(x, D, **kw)
+    t, k, c = cmp.lastResult.events[0]
+    if not np.all(np.isfinite(res)):
+        # a diverging pursuit (filters longer than the signal: the reflect-padded re-correlation feeds on itself until
+        # the residual overflows): identical up to the overflow, the order of inf / NaN comparisons after it is not pinned
+        n = min(len(t), len(info['t'])) - 2
+        assert n > 0 and np.array_equal(t[:n], info['t'][:n]) and np.array_equal(k[:n], info['k'][:n]) and np.array_equal(c[:n], info['c'][:n])
+        return
+    tag = (i, cmp.lastResult.variant, x.shape, D.shape, {a: b for a, b in kw.items() if a != 'weights'})
+    assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']), tag
+    assert np.array_equal(c, info['c']), tag
+    assert np.array_equal(residual, res), tag
+    assert (coefficients != coef).nnz == 0, tag
+    assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
