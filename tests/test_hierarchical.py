@@ -191,3 +191,40 @@ def test_hierarchical_medium_generated_data_vs_reference(name):
         assert gu.rel_err(data, z['case_%s__level%d_data' % (name, l)]) <= 1e-5
     e = float(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
     assert abs(e - float(z['case_%s__residual_energy' % name])) <= 1e-5 * float(z['case_%s__residual_energy' % name])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed, monkeypatch):
+    """Random generated dictionaries / signals / parameters: the GPU hierarchical encoder (per-signal path and the
+    device-chained batch path) against the same host logic driven by the CPU oracle as its level coder -- bit for
+    bit, all levels."""
+    from hsc_amd.dataset import MultilevelDictionaryGenerator, SignalGenerator
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    rs = np.random.RandomState(500 + seed)
+    nlev = 2 + (seed % 2)
+    scales = [int(rs.choice([8, 12, 16]))]
+    for _ in range(nlev - 1):
+        scales.append(scales[-1] * 2 + int(rs.randint(0, 5)))
+    counts = [int(rs.randint(4, 9)) for _ in range(nlev)]
+    mld = MultilevelDictionaryGenerator(rs).generate(scales=scales, counts=counts, decompositionSize=int(rs.randint(2, 4)),
+                                                     multilevelDecomposition=False, maxNbPatternsConsecutiveRejected=30)
+    T = int(rs.randint(20, 60)) * scales[-1]
+    gen = SignalGenerator(mld, [0.02 / (l + 1) for l in range(nlev)], rng=rs)
+    xs = np.stack([gen.generateSignalFromEvents(gen.generateEvents(T), nbSamples=T) for _ in range(3)])
+    xs = (xs + 0.01 * rs.standard_normal(xs.shape)).astype(np.float32)
+    mlds = mld.withSingletonBases()
+    kw = dict(toleranceSnr=[float(rs.uniform(8, 16)) for _ in range(nlev)], nbBlocks=[1, 3, 'auto'][seed % 3],
+              singletonWeight=float(rs.uniform(0.8, 0.95)))
+    gpu = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    ref = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    monkeypatch.setattr(ref, '_level_coder', lambda D: _OracleLevelCoder(D))
+    coefs_b, residuals_b, timings = gpu.computeCoefficientsBatch(xs, mlds, **kw)
+    for b in range(xs.shape[0]):
+        exp_c, exp_r = ref.computeCoefficients(xs[b], mlds, **kw)
+        got_c, got_r = gpu.computeCoefficients(xs[b], mlds, **kw)
+        for l in range(nlev):
+            assert (scipy.sparse.csc_matrix(got_c[l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (seed, b, l, 'per-signal')
+            assert (scipy.sparse.csc_matrix(coefs_b[b][l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (seed, b, l, 'batch')
+        assert np.array_equal(got_r, exp_r) and np.array_equal(residuals_b[b], exp_r)
+    gpu.close()
