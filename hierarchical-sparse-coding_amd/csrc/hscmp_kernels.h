@@ -438,6 +438,37 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
     return p;
 }
 
+// The same energy by ONE wave, bit for bit: lane l carries the four strided partial sums l, 64+l, 128+l, 192+l
+// (what threads l, 64+l, ... of the workgroup version carry), runs the per-wave halving tree on each and
+// combines them as (P0+P1)+(P2+P3).  No workgroup barrier: the weak-atom filter gives every wave its own
+// candidates.  Result valid in lane 0.
+template <typename R>
+__device__ __forceinline__ R wave_window_energy(const DevParams& P, const Sig<R>& G, int t, int& len, int lane)
+{
+    int s, e, es;
+    len = centered_span(P.T, P.W, t, s, e, es);
+    R p0 = (R)0, p1 = (R)0, p2 = (R)0, p3 = (R)0;
+    if (len > 0) {
+        const int n = len * P.F;
+        const R* v = G.r + (int64_t)s * P.F;
+        for (int i0 = lane; i0 < n; i0 += kThreads) {          // element i belongs to partial i mod 256
+            const R x0 = v[i0];
+            const R x1 = i0 + 64 < n ? v[i0 + 64] : (R)0;
+            const R x2 = i0 + 128 < n ? v[i0 + 128] : (R)0;
+            const R x3 = i0 + 192 < n ? v[i0 + 192] : (R)0;
+            const R s0 = x0 * x0, s1 = x1 * x1, s2 = x2 * x2, s3 = x3 * x3;
+            p0 = p0 + s0; p1 = p1 + s1; p2 = p2 + s2; p3 = p3 + s3;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const R o0 = __shfl_down(p0, m), o1 = __shfl_down(p1, m), o2 = __shfl_down(p2, m), o3 = __shfl_down(p3, m);
+        p0 = p0 + o0; p1 = p1 + o1; p2 = p2 + o2; p3 = p3 + o3;
+    }
+    const R a01 = p0 + p1, a23 = p2 + p3;
+    return a01 + a23;
+}
+
 // ------------------------------------------------------------------------------------------------
 // GenericRecorr: re-correlate rows p-(W-1)..p+(W-1) against the reflect-padded residual span
 // (modeling.py:1018-1051), reduce each row to its per-position best, write best_c/best_k.
@@ -693,12 +724,25 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if (P.has_snr && n > 1) {
                 const R tol_energy = sh.e_sig / (R)P.snr_ratio;
                 const double thr = (double)tol_energy / (double)((int64_t)T * F);
-                for (int i = 0; i < n; ++i) {
-                    int len;
-                    const R e = block_window_energy(P, G, sh, ord_t[i], len);
-                    if (tid == 0) {
-                        const R mean = e / (R)((int64_t)len * F);
-                        raw_t[i] = ((double)mean >= thr) ? 1 : 0;      // keep flag (raw half is free now)
+                if (W * F <= 4 * kThreads) {
+                    // short windows: one wave per candidate, no workgroup barriers (same sums, see wave_window_energy)
+                    for (int i = wv; i < n; i += kWaves) {
+                        int len;
+                        const R e = wave_window_energy(P, G, ord_t[i], len, lane);
+                        if (lane == 0) {
+                            const R mean = e / (R)((int64_t)len * F);
+                            raw_t[i] = ((double)mean >= thr) ? 1 : 0;      // keep flag (raw half is free now)
+                        }
+                    }
+                } else {
+                    // long windows (multi-feature inputs): the whole workgroup streams each window
+                    for (int i = 0; i < n; ++i) {
+                        int len;
+                        const R e = block_window_energy(P, G, sh, ord_t[i], len);
+                        if (tid == 0) {
+                            const R mean = e / (R)((int64_t)len * F);
+                            raw_t[i] = ((double)mean >= thr) ? 1 : 0;
+                        }
                     }
                 }
                 __syncthreads();
