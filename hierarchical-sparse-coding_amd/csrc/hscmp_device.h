@@ -34,6 +34,13 @@ __device__ unsigned long long g_cnt[16];         // free-form event counters of 
 #endif
 
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// outstanding global stores (vmcnt), which costs a full memory round trip per barrier
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxSeg = 1024;   // segment maxima kept in LDS per signal

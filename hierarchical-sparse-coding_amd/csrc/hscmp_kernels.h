@@ -808,13 +808,19 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                     int si = maybe_dup ? sh.found : -1;
                     if (si >= 0 && fabs(G.slot_a[si]) > 0.0) sh.ndup += 1;
                     else if (rabs(c) > (R)0) sh.nnz += 1;
-                    if (si < 0) { si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; G.slot_a[si] = 0.0; new_slot = true; }
-                    G.slot_a[si] += (double)c;
+                    if (si < 0) {
+                        si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; new_slot = true;
+                        G.slot_a[si] = 0.0 + (double)c;                 // (:992 starts the accumulator at 0.0)
+                    } else {
+                        G.slot_a[si] += (double)c;
+                    }
                     const int e = sh.nev++;
                     G.ev_t[e] = p; G.ev_k[e] = k; G.ev_c[e] = c;
                 }
             }
-            __syncthreads();
+            // LDS-only barrier: nobody waits for thread 0's list stores here (the duplicate search that reads the
+            // slot list comes after later full barriers), only for the control block
+            lds_barrier();
             // the filter is updated only now: every thread has read this atom's bit (maybe_dup) before the barrier
             // above, and the next read comes after the barriers of the residual update
             if (new_slot) sh.bloom[hb >> 5] |= 1u << (hb & 31);

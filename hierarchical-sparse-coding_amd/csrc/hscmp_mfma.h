@@ -309,13 +309,6 @@ __device__ __forceinline__ double wave_bcast(double v, int src)
     return __longlong_as_double(((long long)hi << 32) | (long long)lo);
 }
 
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
-// outstanding global stores (vmcnt), which costs a full memory round trip per barrier
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ int dimg_index(int k, int w, int S4)
 {
     // float index of D[k][w] inside Dimg[g][s4][lane][q]  (see mfma_build_dict_image)
