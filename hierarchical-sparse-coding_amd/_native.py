@@ -22,7 +22,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
-           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_encode_batch',
+           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
@@ -79,6 +79,7 @@ def load_library():
                                             ctypes.POINTER(ctypes.c_int32)]
     lib.hscmp_update_inner_products.argtypes = [vp, vp, vp, ci, ci]
     lib.hscmp_assign_windows.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+    lib.hscmp_host_slots_to_csc.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_double, vp, vp, vp]
     lib.hscmp_host_overlap_add.argtypes = [vp, ctypes.c_int64, ci, vp, vp, vp, ctypes.c_int64, vp, ci, ci]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]

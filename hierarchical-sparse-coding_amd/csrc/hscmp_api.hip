@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace hscmp;
@@ -833,6 +834,49 @@ extern "C" int hscmp_host_overlap_add(double* signal, int64_t T, int Fd, const i
         } else {
             const double* src = (const double*)D + cols[i] * atom + w0 * Fd;
             for (int64_t e = 0; e < (w1 - w0) * Fd; ++e) dst[e] += c * src[e];
+        }
+    }
+    return HSCMP_OK;
+}
+
+// Host-side CSC assembly of one signal's coefficient slots (modeling.py:1171-1181): drop zeros and |a| < min_coefficients
+// (NaN: no clip), order by (atom, position).  indptr [K+1], indices / data [n] (first indptr[K] entries used).
+// Slots are distinct (t, k) pairs, so there is nothing to sum.  Plain host code.
+extern "C" int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slot_k, const double* slot_a, int64_t n, int K,
+                                       double min_coefficients, int32_t* indptr, int32_t* indices, double* data)
+{
+    if (n < 0 || K <= 0 || !indptr || (n > 0 && (!slot_t || !slot_k || !slot_a || !indices || !data))) return HSCMP_ERR_INVALID;
+    const bool clip = !std::isnan(min_coefficients);
+    std::vector<int64_t> keep;
+    keep.reserve((size_t)n);
+    for (int k = 0; k <= K; ++k) indptr[k] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = slot_a[i];
+        if (a == 0.0 || (clip && !(std::fabs(a) >= min_coefficients))) continue;
+        if (slot_k[i] < 0 || slot_k[i] >= K) return HSCMP_ERR_INVALID;
+        keep.push_back(i);
+        indptr[slot_k[i] + 1] += 1;
+    }
+    for (int k = 0; k < K; ++k) indptr[k + 1] += indptr[k];
+    std::vector<int32_t> cur(indptr, indptr + K);
+    for (int64_t i : keep) {                       // counting sort by atom ...
+        const int32_t o = cur[slot_k[i]]++;
+        indices[o] = slot_t[i]; data[o] = slot_a[i];
+    }
+    for (int k = 0; k < K; ++k) {                  // ... then by position inside each column (short runs: insertion sort)
+        const int32_t b0 = indptr[k], b1 = indptr[k + 1];
+        if (b1 - b0 > 64) {
+            std::vector<std::pair<int32_t, double>> col((size_t)(b1 - b0));
+            for (int32_t j = b0; j < b1; ++j) col[(size_t)(j - b0)] = {indices[j], data[j]};
+            std::sort(col.begin(), col.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
+            for (int32_t j = b0; j < b1; ++j) { indices[j] = col[(size_t)(j - b0)].first; data[j] = col[(size_t)(j - b0)].second; }
+        } else {
+            for (int32_t j = b0 + 1; j < b1; ++j) {
+                const int32_t ti = indices[j]; const double av = data[j];
+                int32_t q = j;
+                while (q > b0 && indices[q - 1] > ti) { indices[q] = indices[q - 1]; data[q] = data[q - 1]; --q; }
+                indices[q] = ti; data[q] = av;
+            }
         }
     }
     return HSCMP_OK;

@@ -15,6 +15,8 @@ MI355X the calls raise hsc_amd._native.HscmpError.
 """
 import logging
 
+import ctypes
+
 import numpy as np
 import scipy.sparse
 
@@ -155,13 +157,22 @@ class SparseApproximator(object):
 
 
 def _slots_to_csc(slot_t, slot_k, slot_a, n, shape, minCoefficients):
-    """hsc/modeling.py:1171-1181: clip |c| < minCoefficients, CSC, eliminate zeros."""
-    t, k, a = slot_t[:n], slot_k[:n], slot_a[:n]
-    keep = a != 0.0
-    if minCoefficients is not None:
-        keep &= np.abs(a) >= minCoefficients
-    m = scipy.sparse.csc_matrix((a[keep].astype(np.float64), (t[keep].astype(np.int64), k[keep].astype(np.int64))), shape=shape)
-    m.sort_indices()
+    """hsc/modeling.py:1171-1181: clip |c| < minCoefficients, CSC, eliminate zeros (assembled by the native
+    library: hscmp_host_slots_to_csc)."""
+    lib = _native.load_library()
+    n = int(n)
+    t = np.ascontiguousarray(slot_t[:n], dtype=np.int32); k = np.ascontiguousarray(slot_k[:n], dtype=np.int32)
+    a = np.ascontiguousarray(slot_a[:n], dtype=np.float64)
+    indptr = np.empty((shape[1] + 1,), dtype=np.int32)
+    indices = np.empty((max(n, 1),), dtype=np.int32); data = np.empty((max(n, 1),), dtype=np.float64)
+    minc = float('nan') if minCoefficients is None else float(minCoefficients)
+    rc = lib.hscmp_host_slots_to_csc(_native._ptr(t), _native._ptr(k), _native._ptr(a), n, int(shape[1]), ctypes.c_double(minc),
+                                     _native._ptr(indptr), _native._ptr(indices), _native._ptr(data))
+    if rc != 0:
+        raise _native.HscmpError('hscmp_host_slots_to_csc failed (%d)' % rc)
+    nnz = int(indptr[-1])
+    m = scipy.sparse.csc_matrix((data[:nnz], indices[:nnz], indptr), shape=shape, copy=False)
+    m.has_sorted_indices = True
     return m
 
 

@@ -150,6 +150,13 @@ int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, int L, int3
 int hscmp_host_overlap_add(double* signal, int64_t T, int Fd, const int64_t* rows, const int64_t* cols, const double* data,
                            int64_t n, const void* D, int W, int dict_is_f32);
 
+/* Host-side CSC assembly of one signal's coefficient slots (the epilogue of computeCoefficients, modeling.py:
+ * 1171-1181): entries that are zero or below min_coefficients (NaN: no clip) are dropped, the rest ordered by
+ * (atom, position).  indptr int32 [K+1]; indices int32 / data float64 with room for n entries, of which the first
+ * indptr[K] are written.  No GPU work, no context. */
+int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slot_k, const double* slot_a, int64_t n, int K,
+                            double min_coefficients, int32_t* indptr, int32_t* indices, double* data);
+
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
  * between rounds.  max_rounds <= 0: until converged. */
