@@ -32,6 +32,7 @@ struct hscmp_ctx {
     void* d_w = nullptr;      // nullptr when no weights
     void* d_Dfrag = nullptr;  // MFMA fragment-ordered copy (f32, F == 1)
     void* d_Dt = nullptr;     // [W][F][K] transposed copy for the sparsity-aware kernels (F > 1)
+    void* d_Dc = nullptr;     // [K][F][W] chain-ordered copy for the dense chains (F > 1)
     void* d_scratch = nullptr;
     int* d_nzptr = nullptr;   // CSR of the dictionary's non-zeros per atom, chain order (sparse level dictionaries)
     int* d_nzwf = nullptr;
@@ -117,7 +118,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 
 static void free_all(hscmp_ctx* c)
 {
-    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
+    void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_Dc, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
                     c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -163,6 +164,7 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     if (ctx->d_w) { (void)hipFree(ctx->d_w); ctx->d_w = nullptr; }
     if (ctx->d_Dfrag) { (void)hipFree(ctx->d_Dfrag); ctx->d_Dfrag = nullptr; ctx->Dfrag_bytes = 0; }
     if (ctx->d_Dt) { (void)hipFree(ctx->d_Dt); ctx->d_Dt = nullptr; }
+    if (ctx->d_Dc) { (void)hipFree(ctx->d_Dc); ctx->d_Dc = nullptr; }
     if (ctx->d_nzptr) { (void)hipFree(ctx->d_nzptr); ctx->d_nzptr = nullptr; }
     if (ctx->d_nzwf) { (void)hipFree(ctx->d_nzwf); ctx->d_nzwf = nullptr; }
     if (ctx->d_nzval) { (void)hipFree(ctx->d_nzval); ctx->d_nzval = nullptr; }
@@ -186,6 +188,13 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
                     memcpy(&dt[(((size_t)w * F + f) * K + k) * es], (const char*)D + (((size_t)k * W + w) * F + f) * es, es);
         HIP_TRY(ctx, hipMalloc(&ctx->d_Dt, nD));
         HIP_TRY(ctx, hipMemcpy(ctx->d_Dt, dt.data(), nD, hipMemcpyHostToDevice));
+        // Dc[k][f][w] = D[k][w][f]: consecutive addresses along the pinned chain (f outer, w inner)
+        for (int k = 0; k < K; ++k)
+            for (int w = 0; w < W; ++w)
+                for (int f = 0; f < F; ++f)
+                    memcpy(&dt[(((size_t)k * F + f) * W + w) * es], (const char*)D + (((size_t)k * W + w) * F + f) * es, es);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_Dc, nD));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Dc, dt.data(), nD, hipMemcpyHostToDevice));
         // per-atom list of non-zeros in chain order (f outer, w inner), kept when the dictionary is sparse
         // (level dictionaries built from decompositions + singletons, hsc/dataset.py:137-194, 826-860)
         if (W <= 32767 && F <= 65535 && !getenv("HSCMP_NO_DICT_LISTS")) {
@@ -346,6 +355,7 @@ template <typename R> static State<R> make_state(hscmp_ctx* c)
 {
     State<R> S;
     S.D = (const R*)c->d_D; S.weights = (const R*)c->d_w;
+    S.Dc = c->d_Dc ? (const R*)c->d_Dc : (const R*)c->d_D;
     S.residual = (R*)c->d_resid; S.best_c = (R*)c->d_best_c; S.best_k = c->d_best_k;
     S.ev_t = c->d_ev_t; S.ev_k = c->d_ev_k; S.ev_c = (R*)c->d_ev_c;
     S.slot_t = c->d_slot_t; S.slot_k = c->d_slot_k; S.slot_a = c->d_slot_a;
@@ -426,8 +436,9 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
     DevParams P = P0;
     set_segments(P, GenericRecorr<R>::kMaxSegments);
     const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
-    hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S,
-                       typename GenericRecorr<R>::Args{});
+    auto kern = iterate_kernel<R, GenericRecorr<R>>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
     return HSCMP_OK;
 }
 
@@ -473,7 +484,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     }
     const bool spl = !mfi && use_sparse_loop(ctx);
     if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
-    else if (!mfi) launch_iterate<R>(ctx, P);
+    else if (!mfi) { int rc = launch_iterate<R>(ctx, P); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
@@ -578,7 +589,10 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
     if (!mfi && use_sparse_loop(ctx)) {
         int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);
         if (rc) return rc;
-    } else if (!mfi) { if (ctx->dtype == HSCMP_F32) launch_iterate<float>(ctx, P); else launch_iterate<double>(ctx, P); }
+    } else if (!mfi) {
+        int rc = ctx->dtype == HSCMP_F32 ? launch_iterate<float>(ctx, P) : launch_iterate<double>(ctx, P);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -751,6 +765,7 @@ template <typename R> static int run_convolve(hscmp_ctx* ctx, const void* x, int
         P.B = 1; P.T = T; P.K = K; P.W = W; P.F = F; P.off = (W - 1) / 2;
         State<R> S{};
         S.D = (const R*)ctx->d_D; S.weights = nullptr;
+        S.Dc = ctx->d_Dc ? (const R*)ctx->d_Dc : (const R*)ctx->d_D;
         dim3 grid((Tout + kThreads - 1) / kThreads, 1);
         hipLaunchKernelGGL((corr_init_generic_kernel<R, true>), grid, dim3(kThreads), 0, ctx->stream, P, S, (const R*)dx,
                            same ? P.off : 0, Tout, dout);
@@ -928,7 +943,7 @@ static int run_select(hscmp_ctx* ctx, const void* ip, int T, int K, int W, int n
                 if ((e = hipMemcpyAsync(d_w, weights, (size_t)K * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
             }
             State<R> S = make_state<R>(ctx);
-            S.D = nullptr; S.weights = d_w;
+            S.D = nullptr; S.Dc = nullptr; S.weights = d_w;
             hipLaunchKernelGGL((table_to_best_kernel<R>), dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
                                (const R*)d_ip, T, K, (const R*)d_w, S.best_c, S.best_k);
             int st[ST_COUNT] = {0};
@@ -937,8 +952,9 @@ static int run_select(hscmp_ctx* ctx, const void* ip, int T, int K, int W, int n
             P.select_only = 1; P.has_snr = 0; P.has_scale = 0;
             set_segments(P, GenericRecorr<R>::kMaxSegments);
             const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
-            hipLaunchKernelGGL((iterate_kernel<R, GenericRecorr<R>>), dim3(1), dim3(kThreads), lds, ctx->stream, P, S,
-                               typename GenericRecorr<R>::Args{});
+            auto kern = iterate_kernel<R, GenericRecorr<R>>;
+            if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) break;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
             if ((e = hipGetLastError()) != hipSuccess) break;
             if ((e = hipMemcpyAsync(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
             if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) break;

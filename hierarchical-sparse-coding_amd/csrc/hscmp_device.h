@@ -84,6 +84,7 @@ enum { STOP_RUNNING = 0, STOP_ENERGY_EPS = 1, STOP_NNZ = 2, STOP_SNR = 3, STOP_S
 
 template <typename R> struct State {
     const R* D;         // [K][W][F]
+    const R* Dc;        // [K][F][W]: the same dictionary in chain order (f outer, w inner); == D when F == 1
     const R* weights;   // [K] or nullptr
     R* residual;        // [B][T*F]
     R* best_c;          // [B][T]

@@ -516,6 +516,7 @@ template <typename R> struct GenericRecorr {
         if (ngrp > K) ngrp = K;
         if (ngrp < 1) ngrp = 1;
         const R* __restrict__ D = S.D;
+        const R* __restrict__ Dc = S.Dc;                    // [K][F][W]: consecutive along the chain
         for (int base = 0; base < nrows; base += rpp) {
             const int j = base + tid % rpp;
             const int g = tid / rpp;
@@ -531,9 +532,10 @@ template <typename R> struct GenericRecorr {
                     R acc = (R)0;
                     if (staged) {
                         const R* wj = win + j;                       // row j's window starts at span row j
+                        const R* dc = Dc + (int64_t)k * W * F;
                         for (int f = 0; f < F; ++f) {
 #pragma unroll 8
-                            for (int w = 0; w < W; ++w) acc = rfma(wj[f * span + w], dk[w * F + f], acc);
+                            for (int w = 0; w < W; ++w) acc = rfma(wj[f * span + w], dc[f * W + w], acc);
                         }
                     } else {
                         for (int f = 0; f < F; ++f)
