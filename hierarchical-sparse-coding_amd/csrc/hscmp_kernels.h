@@ -484,6 +484,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
+    static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -828,6 +829,9 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if (new_slot) sh.bloom[hb >> 5] |= 1u << (hb & 31);
             if (sh.skip) break;
             if constexpr (!Recorr::kFused) HSCMP_STAMP(33);
+
+            // (policy hook: work that only needs to know the atom, overlapped with the residual update below)
+            Recorr::on_atom(P, S, A, plds, p, k);
 
             // ---- :1117, :996-1016 residual subtract with local energy before / after
             int s, e, es;

@@ -534,6 +534,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     using R = typename Tile::R;
     static constexpr int TP = Tile::TP;
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const MfmaArgsT<R>&, char*) { return S.weights; }
+    static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const MfmaArgsT<R>&, char*, int, int) {}
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
 

@@ -536,18 +536,16 @@ template <typename R> struct SparseRecorr {
     }
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
-    template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
-                                               char* lds, int p, int k)
+    // The cells the selected atom touches may be non-zero after its subtraction: add them to their rows' lists.
+    // Issued before the residual update so that its memory round trips overlap with it; the window gather of
+    // run() comes several barriers later.  (Distinct (w, f) of one atom are distinct cells, so no two threads
+    // append the same member.)
+    static __device__ __forceinline__ void on_atom(const DevParams& P, const State<R>&, const Args& A0, char* lds, int p, int k)
     {
-        HSCMP_STAMP_BEGIN();
-        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
-        const int T = P.T, W = P.W;
+        if (!A0.rl_cnt) return;
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
-        unsigned* bits = has_bits(P, A) ? bits_of(P, A0, lds) : nullptr;
-        if (A.rl_cnt) {
-            // the cells the subtracted atom touched may be non-zero now: add them to their rows' lists
-            // (distinct (w, f) of one atom are distinct cells, so no two threads append the same member)
+        const int T = P.T;
+        {
             const int C = A.rl_cap;
             int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
             int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
@@ -571,6 +569,19 @@ template <typename R> struct SparseRecorr {
                     if (o < C) lf[(int64_t)g * C + o] = f;
                 }
             }
+        }
+    }
+    template <typename SH>
+    static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
+                                               char* lds, int p, int k)
+    {
+        HSCMP_STAMP_BEGIN();
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        const int T = P.T, W = P.W;
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        unsigned* bits = has_bits(P, A) ? bits_of(P, A0, lds) : nullptr;
+        if (A.rl_cnt) {
+            // (the atom's cells were added to the row lists by on_atom(), before the residual update)
         } else if (bits) {
             // the atom just subtracted made its span possibly non-zero (utils.py:76-131)
             int s, e, es;
