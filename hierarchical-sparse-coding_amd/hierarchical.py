@@ -153,7 +153,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         per-level kernel timings)."""
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
-            raise NotImplementedError("computeCoefficientsBatch runs the greedy engine only: method='cmp'")
+            # LoCOMP is a host-driven loop around the GPU hooks: signal by signal
+            out = [self.computeCoefficients(sequences[b], multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
+                                            singletonWeight=singletonWeight, returnDistributed=returnDistributed)
+                   for b in range(sequences.shape[0])]
+            return [o[0] for o in out], np.stack([o[1] for o in out], axis=0), []
         from . import _native
         from .modeling import _compute_dtype, _slots_to_csc
         nbLevels = multilevelDict.getNbLevels()

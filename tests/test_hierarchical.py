@@ -228,3 +228,20 @@ def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed,
             assert (scipy.sparse.csc_matrix(coefs_b[b][l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (seed, b, l, 'batch')
         assert np.array_equal(got_r, exp_r) and np.array_equal(residuals_b[b], exp_r)
     gpu.close()
+
+
+@pytest.mark.gpu
+def test_hierarchical_batch_with_locomp_runs_signal_by_signal():
+    """The batch entry point with the reference's default method ('locomp', a host loop around the GPU hooks)."""
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+    z = _golden()
+    mld = _mld().withSingletonBases()
+    xs = np.stack([z['x'], (z['x'][::-1]).copy()])
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method='locomp')
+    kw = dict(toleranceSnr=[10.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.5)
+    coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
+    for b in range(2):
+        c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
+        for l in range(3):
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(c1[l])).nnz == 0
+        assert np.array_equal(residuals[b], r1)
