@@ -333,7 +333,7 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_sel_c, &ctx->caps[12], B * 2 * ms * es},
         {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
         {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
-        {(void**)&ctx->d_edge, &ctx->caps[15], B * 2 * sizeof(unsigned long long)},
+        {(void**)&ctx->d_edge, &ctx->caps[15], B * kEdgeWords * sizeof(unsigned long long)},
         {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)sparse_init_split(P.B, P.T, P.W) * (2 * P.W - 1) * P.K * es : 0},
         {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, ctx->F > 1 ? B * T : 0},
         {(void**)&ctx->d_rl_cnt, &ctx->cap_rl_cnt, use_row_lists(ctx) ? B * T * sizeof(int) : 0},

@@ -41,6 +41,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+constexpr int kEdgeWords = 4;    // per signal: left mask, right mask, stale sample index + 1 (0: none), its saved bits
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxSeg = 1024;   // segment maxima kept in LDS per signal
@@ -94,7 +95,7 @@ template <typename R> struct State {
     int* sel_t; int* sel_k; R* sel_c;         // [B][2*maxsel]  (two halves: raw / ordered)
     int* stats;         // [B][ST_COUNT]
     R* energy;          // [B][2]: signal, residual
-    unsigned long long* edge;   // [B][2]: edge rows re-correlated at least once (score-only policies)
+    unsigned long long* edge;   // [B][kEdgeWords]: edge rows re-correlated at least once + the stale-sample record (score-only policies)
 };
 
 __device__ __forceinline__ float rabs(float v) { return fabsf(v); }

@@ -44,8 +44,7 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(DevParams P, State<R>
         S.energy[2 * b + 1] = p;
         int* st = S.stats + (int64_t)b * ST_COUNT;
         for (int i = 0; i < ST_COUNT; ++i) st[i] = 0;
-        S.edge[2 * b + 0] = 0ull;
-        S.edge[2 * b + 1] = 0ull;
+        for (int i = 0; i < kEdgeWords; ++i) S.edge[kEdgeWords * b + i] = 0ull;
     }
 }
 
@@ -98,8 +97,7 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
         S.energy[2 * b + 1] = p;
         int* st = S.stats + (int64_t)b * ST_COUNT;
         for (int i = 0; i < ST_COUNT; ++i) st[i] = 0;
-        S.edge[2 * b + 0] = 0ull;
-        S.edge[2 * b + 1] = 0ull;
+        for (int i = 0; i < kEdgeWords; ++i) S.edge[kEdgeWords * b + i] = 0ull;
     }
 }
 

@@ -345,12 +345,28 @@ __device__ __forceinline__ float resolve_chain(const float* __restrict__ dimg, c
 // sample.  Outside: the initial table is ZERO padded (modeling.py:159-164) but every local update
 // REFLECT pads (modeling.py:1046), so a row that has been re-correlated at least once (edge bit set)
 // sees r reflected about 0 / T-1, an untouched one sees 0.  (T >= 3W-2 on this path: one bounce.)
+//
+// One reflected sample can be STALE in the reference's table: with an even W, row T-1 reads r[T-1-W/2]
+// through the reflection, an atom at p = T-1-W changes that sample, but only re-correlates rows up to T-2
+// (:1028-1049).  The reference keeps row T-1 as it was; so does the score kept here, and the resolution
+// of (k, c) must see the old sample too: edge[2] = its index + 1 (0: nothing stale), edge[3] = its bits,
+// recorded by the update and dropped when row T-1 is re-correlated.  (No other row / sample / side can
+// go stale: for row t < T-1, for odd W and at the left edge every update that changes a reflected sample
+// also re-correlates the rows that read it.)
+__device__ __forceinline__ float edge_bits_to(unsigned long long b, float) { return __uint_as_float((unsigned)b); }
+__device__ __forceinline__ double edge_bits_to(unsigned long long b, double) { return __longlong_as_double((long long)b); }
+__device__ __forceinline__ unsigned long long edge_bits_of(float v) { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ unsigned long long edge_bits_of(double v) { return (unsigned long long)__double_as_longlong(v); }
+
 template <typename R>
 __device__ __forceinline__ R edge_window_value(const R* __restrict__ r, int T, int g, int p, const unsigned long long* edge)
 {
     if (g >= 0 && g < T) return r[g];
     if (g < 0) return ((edge[0] >> p) & 1ull) ? r[-g] : (R)0;
-    return ((edge[1] >> (T - 1 - p)) & 1ull) ? r[2 * (T - 1) - g] : (R)0;
+    if (!((edge[1] >> (T - 1 - p)) & 1ull)) return (R)0;
+    const int m = 2 * (T - 1) - g;
+    if (p == T - 1 && edge[2] == (unsigned long long)(m + 1)) return edge_bits_to(edge[3], (R)0);
+    return r[m];
 }
 
 __device__ __forceinline__ unsigned long long bit_range(int a, int b)     // bits a..b (0 <= a <= b <= 63)
@@ -550,7 +566,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     {
         const size_t relems = (size_t)A.G * A.S4 * Tile::kChunkElems + (HAS_W ? Tile::GA * A.G : 0) + window_floats(P.W, A.S4) +
                               2 * 8 * A.S4 + (size_t)segbuf_len(P.W, P.seg) + 8 * A.S4 + kWaves * 8 * A.S4;
-        return relems * sizeof(R) + kBloomWords * sizeof(unsigned) + 2 * sizeof(unsigned long long);
+        return relems * sizeof(R) + kBloomWords * sizeof(unsigned) + kEdgeWords * sizeof(unsigned long long);
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
@@ -581,7 +597,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = (R)0;   // the tail behind the span stays zero
         for (int i = threadIdx.x; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
         for (int i = threadIdx.x; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = (R)0;   // padded taps stay zero
-        if (threadIdx.x < 2) L.edge[threadIdx.x] = S.edge[2 * b + threadIdx.x];
+        if (threadIdx.x < kEdgeWords) L.edge[threadIdx.x] = S.edge[kEdgeWords * b + threadIdx.x];
         __syncthreads();
         // resumed launch: re-enter the (t,k) pairs selected so far
         const int nslots = S.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
@@ -597,7 +613,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>& S, const Args& A, char* lds)
     {
         const Layout L = layout(P, A, lds);
-        if (threadIdx.x < 2) S.edge[2 * blockIdx.x + threadIdx.x] = L.edge[threadIdx.x];
+        if (threadIdx.x < kEdgeWords) S.edge[kEdgeWords * blockIdx.x + threadIdx.x] = L.edge[threadIdx.x];
     }
 
     // never reached: iterate_kernel hands the whole atom body to apply_atom() when kFused
@@ -739,6 +755,12 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
                     const R prod = nc * L.dimg[Tile::dindex(k, es + q, S4)];   // -c*D[k] rounded, then += (utils.py:120,129)
                     const R vn = v + prod;
                     if (tstart + i == m) {                    // the sample itself (not a reflected copy)
+                        // even W: an atom at T-1-W changes the sample that row T-1 reads through the reflection
+                        // without re-correlating that row -- keep what row T-1 saw (see edge_window_value)
+                        if (!(W & 1) && p == T - 1 - W && m == T - 1 - W / 2 && (L.edge[1] & 1ull) && L.edge[2] == 0ull) {
+                            L.edge[3] = edge_bits_of(v);
+                            L.edge[2] = (unsigned long long)(m + 1);
+                        }
                         Gs.r[m] = vn;
                         L.esq[q] = v * v;
                         L.esq[L.wp + q] = vn * vn;
@@ -816,6 +838,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             if (lo < P.off) L.edge[0] |= bit_range(lo, min(hi, P.off - 1));
             const int rt0 = T - (W - 1 - P.off);                // first position whose window passes T-1
             if (hi >= rt0) L.edge[1] |= bit_range(T - 1 - hi, T - 1 - max(lo, rt0));
+            if (hi >= T - 1) L.edge[2] = 0ull;                  // row T-1 re-correlated: nothing stale any more
             if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
             else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
             else if (P.has_snr) {

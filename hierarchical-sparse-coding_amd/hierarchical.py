@@ -180,10 +180,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 stats = eng.fetch_stats()
                 if not np.any(stats[:, _native.STAT_STOP] == _native.STOP_CAPACITY):
                     break
-                maxEvents *= 4                       # enlarge the event lists and resume (exact, see hscmp_grow_events)
-                if maxEvents > _native.max_event_capacity(T):
-                    raise _native.HscmpError('the pursuit does not converge: more than %d selections per signal without meeting a '
-                                             'stop rule (the reference would not terminate)' % (maxEvents // 4))
+                bound = _native.max_event_capacity(T)
+                if maxEvents >= bound:
+                    raise _native.HscmpError('the pursuit does not converge: more than %d selections per signal without meeting a stop '
+                                             'rule (the same atoms are re-selected; the reference would not terminate)' % maxEvents)
+                maxEvents = min(4 * maxEvents, bound)          # enlarge the event lists and resume (exact, see hscmp_grow_events)
                 eng.grow_events(maxEvents)
                 eng.continue_rounds(0)
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])

@@ -283,10 +283,11 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
                 break
             # the event list was too short for this stop rule: enlarge it and resume where the loop stopped
             # (a round is only started when all its atoms fit, so the trace equals an uninterrupted run)
-            maxEvents *= 4
-            if maxEvents > _native.max_event_capacity(T):
+            bound = _native.max_event_capacity(T)
+            if maxEvents >= bound:
                 raise _native.HscmpError('the pursuit does not converge: more than %d selections per signal without meeting a stop '
-                                         'rule (the same atoms are re-selected; the reference would not terminate)' % (maxEvents // 4))
+                                         'rule (the same atoms are re-selected; the reference would not terminate)' % maxEvents)
+            maxEvents = min(4 * maxEvents, bound)          # enlarge the event lists and resume (exact, see hscmp_grow_events)
             eng.grow_events(maxEvents)
             eng.continue_rounds(1 if per_round else 0)
             kernel_ms[2] += eng.last_kernel_ms()[2]
