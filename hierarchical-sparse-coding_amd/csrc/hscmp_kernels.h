@@ -303,6 +303,7 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     int wtot[kWaves];
     // control block (written by thread 0, read by all after a barrier)
     int nsel, converged, stop, found, skip;
+    int nullsel;              // a fused atom body found the selected coefficient null (:974): the round selected nothing
     int nnz, ndup, rounds, iters, nev, nslots, offset;
     int atom_t, atom_k;
     R atom_c;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     if (tid == 0) {
         sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
-        sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1;
+        sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1; sh.nullsel = 0;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
     }
     if constexpr (!Recorr::kFused) {
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             }
         }
         if (tid == 0) {
-            if (nsel == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
+            if (nsel == 0 || sh.nullsel) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }   // (after the scale rule, :1145-1153)
             sh.rounds += 1;
             sh.offset = !sh.offset;
         }

@@ -726,7 +726,8 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) { m = sh.cred[q]; c = sh.red[q]; }
             k = m.i;
             if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
-                if (tid == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
+                // (with a residual-scale rule the reference tests that rule first, :1145-1153: the slow rules name the reason)
+                if (tid == 0) { sh.converged = 1; sh.nullsel = 1; if (!P.has_scale && sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
                 __syncthreads();
                 return true;
             }

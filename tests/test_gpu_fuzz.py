@@ -114,3 +114,32 @@ def test_random_configuration_vs_oracle(i):
     assert np.array_equal(residual, res), tag
     assert (coefficients != coef).nnz == 0, tag
     assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
+
+
+N_BATCHES = int(os.environ.get("HSCMP_FUZZ_BATCHES", "48"))
+
+
+@pytest.mark.parametrize('i', range(N_BATCHES))
+def test_random_batch_vs_oracle(i):
+    """Batches of related signals (scaled, reversed, noisier, all-zero, truncated energy) through the batch entry
+    point: every signal must equal its own single-signal oracle run -- signals converge at different times."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from hsc_amd._native import HscmpError
+    from oracle import hsc_oracle as orc
+    x, D, kw = _draw(20000 + i)
+    rs = np.random.RandomState(777 + i)
+    xs = np.stack([x, 0.5 * x, x[::-1].copy(), np.zeros_like(x), x + (0.1 * rs.standard_normal(x.shape)).astype(x.dtype),
+                   (x * (np.arange(x.shape[0]) < x.shape[0] // 2).reshape((-1,) + (1,) * (x.ndim - 1))).astype(x.dtype)])
+    refs = [orc.cmp_encode(xs[b], D, maxEvents=1 << 17, **kw) for b in range(xs.shape[0])]
+    if any(r[2]['stop'] == 'capacity' or not np.all(np.isfinite(r[1])) for r in refs):
+        return                                              # non-terminating / diverging member: covered by the single-signal sweep
+    cmp = ConvolutionalMatchingPursuit()
+    res = cmp.computeCoefficientsBatch(xs, D, **kw)
+    for b in range(xs.shape[0]):
+        coef, r, info = refs[b]
+        t, k, c = res.events[b]
+        tag = (i, b, res.variant, xs.shape, D.shape)
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), tag
+        assert np.array_equal(res.residuals[b], r), tag
+        assert (res.coefficients[b] != coef).nnz == 0, tag
+        assert res.stop_reasons()[b] == info['stop'], tag
