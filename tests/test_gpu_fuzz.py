@@ -143,3 +143,44 @@ def test_random_batch_vs_oracle(i):
         assert np.array_equal(res.residuals[b], r), tag
         assert (res.coefficients[b] != coef).nnz == 0, tag
         assert res.stop_reasons()[b] == info['stop'], tag
+
+
+N_EDGE = int(os.environ.get("HSCMP_FUZZ_EDGE", "24"))
+
+
+@pytest.mark.parametrize('i', range(N_EDGE))
+def test_medium_signals_with_atoms_piled_at_the_edges(i):
+    """MFMA-sized problems (W up to 64, K up to 256, T a few thousand) whose energy sits at the two borders, where the
+    zero- vs reflect-padding history of the rows matters (edge masks, stale reflected sample): against the oracle."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from oracle import hsc_oracle as orc
+    rs = np.random.RandomState(41000 + i)
+    dtype = np.float32 if i % 2 == 0 else np.float64
+    W = int(rs.choice([8, 16, 32, 33, 64])); K = int(rs.choice([8, 32, 96, 256]))
+    T = int(rs.randint(3 * W, 20 * W + 200))
+    D = rs.standard_normal((K, W)).astype(dtype)
+    D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
+    x = (0.02 * rs.standard_normal(T)).astype(dtype)
+    for _ in range(int(rs.randint(20, 60))):
+        k = rs.randint(0, K); c = rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0])
+        side = rs.randint(0, 3)
+        p = [rs.randint(-W // 2, W + 2), rs.randint(T - 2 * W - 2, T + W // 2), rs.randint(0, T)][side]   # centre, may stick out
+        lo = p - (W - 1) // 2
+        s, e = max(0, lo), min(T, lo + W)
+        if e > s:
+            x[s:e] += (c * D[k][s - lo:e - lo]).astype(dtype)
+    kw = dict(nbNonzeroCoefs=int(rs.randint(30, 160)))
+    if rs.rand() < 0.5:
+        kw['nbBlocks'] = 'auto' if rs.rand() < 0.5 else int(rs.randint(2, 12))
+    if rs.rand() < 0.3:
+        kw['toleranceSnr'] = float(rs.uniform(10, 30))
+    coef, res, info = orc.cmp_encode(x, D, maxEvents=1 << 16, **kw)
+    if info['stop'] == 'capacity' or not np.all(np.isfinite(res)):
+        return
+    cmp = ConvolutionalMatchingPursuit()
+    coefficients, residual = cmp.computeCoefficients(x, D, **kw)
+    t, k, c = cmp.lastResult.events[0]
+    tag = (i, cmp.lastResult.variant, T, K, W, kw)
+    assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), tag
+    assert np.array_equal(residual, res), tag
+    assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
