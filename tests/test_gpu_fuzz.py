@@ -114,6 +114,13 @@ def test_random_configuration_vs_oracle(i):
     assert np.array_equal(residual, res), tag
     assert (coefficients != coef).nnz == 0, tag
     assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
+    if i % 3 == 0:
+        # the same run squeezed through event lists that start far too short (grown in place, loop resumed)
+        small = ConvolutionalMatchingPursuit()
+        r2 = small.computeCoefficientsBatch(x[np.newaxis], D, maxEvents=2, **kw)
+        t2, k2, c2 = r2.events[0]
+        assert np.array_equal(t2, t) and np.array_equal(k2, k) and np.array_equal(c2, c), tag
+        assert np.array_equal(np.squeeze(r2.residuals[0]), np.squeeze(residual)) and r2.stop_reasons()[0] == info['stop'], tag
 
 
 N_BATCHES = int(os.environ.get("HSCMP_FUZZ_BATCHES", "48"))
