@@ -191,3 +191,43 @@ def test_medium_signals_with_atoms_piled_at_the_edges(i):
     assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), tag
     assert np.array_equal(residual, res), tag
     assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
+
+
+N_LEVEL = int(os.environ.get("HSCMP_FUZZ_LEVEL", "6"))
+
+
+@pytest.mark.parametrize('i', range(N_LEVEL))
+def test_level_shaped_medium_problems(i):
+    """Level >= 1 shaped problems at realistic widths (W up to 65, up to 130 features): sparse inputs with a few dense
+    rows, sparse dictionaries with singletons -- bucketed pair sort, LDS list capacities, row-list overflow, dictionary
+    lists too long for LDS."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from oracle import hsc_oracle as orc
+    rs = np.random.RandomState(51000 + i)
+    W = int(rs.choice([9, 16, 33, 65])); F = int(rs.choice([12, 48, 130])); K = int(rs.randint(4, 24))
+    T = int(rs.randint(4 * W, 7 * W + 80))                      # (sized for the oracle, which correlates densely)
+    D = np.zeros((K, W, F))
+    for k in range(K):
+        for _ in range(int(rs.randint(1, 6))):
+            D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+        D[k] /= np.sqrt(np.sum(np.square(D[k])))
+    S = np.zeros((F, W, F)); S[np.arange(F), (W - 1) // 2, np.arange(F)] = 1.0
+    D = np.concatenate((S, D), axis=0)
+    x = np.zeros((T, F))
+    for _ in range(int(rs.randint(T // 20, T // 3))):
+        x[rs.randint(0, T), rs.randint(0, F)] = rs.uniform(0.3, 2.0) * rs.choice([-1.0, 1.0])
+    for t in rs.randint(0, T, size=int(rs.randint(0, 4))):
+        n = min(F, int(rs.randint(9, 30)))
+        x[t, rs.permutation(F)[:n]] = rs.standard_normal(n)            # a dense-ish row: its feature list overflows
+    w = np.ones(D.shape[0]); w[:F] = rs.uniform(0.7, 0.95)
+    kw = dict(toleranceSnr=float(rs.uniform(10, 30)), nbNonzeroCoefs=150, nbBlocks=[1, 4, 10, 'auto'][i % 4], weights=w, minCoefficients=None)
+    coef, res, info = orc.cmp_encode(x, D, maxEvents=600, **kw)     # (the dense oracle is slow here: bounded trace)
+    if info['stop'] == 'capacity' or not np.all(np.isfinite(res)):
+        return
+    cmp = ConvolutionalMatchingPursuit()
+    coefficients, residual = cmp.computeCoefficients(x, D, **kw)
+    t, k, c = cmp.lastResult.events[0]
+    tag = (i, cmp.lastResult.variant, T, K, W, F, len(info['t']))
+    assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), tag
+    assert np.array_equal(residual, res), tag
+    assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
