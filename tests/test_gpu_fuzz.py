@@ -163,7 +163,7 @@ def test_medium_signals_with_atoms_piled_at_the_edges(i):
     from oracle import hsc_oracle as orc
     rs = np.random.RandomState(41000 + i)
     dtype = np.float32 if i % 2 == 0 else np.float64
-    W = int(rs.choice([8, 16, 32, 33, 64])); K = int(rs.choice([8, 32, 96, 256]))
+    W = int(rs.choice([8, 16, 32, 33, 64, 96, 127, 128])); K = int(rs.choice([7, 8, 32, 96, 100, 256]))
     T = int(rs.randint(3 * W, 20 * W + 200))
     D = rs.standard_normal((K, W)).astype(dtype)
     D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
