@@ -362,6 +362,26 @@ def gen_locomp():
         cases.append(('%s_T256_K16_W15_L12' % tag, x, D, dict(nbNonzeroCoefs=12)))
         w = np.ones(16, dtype=dt); w[:4] = 0.5
         cases.append(('%s_T256_K16_W15_snr8_weights' % tag, x, D, dict(toleranceSnr=8.0, nbBlocks=4, weights=w)))
+    # a random family: odd / even widths, multi-feature, both dtypes, every selection mode
+    for q in range(28):
+        dt = np.float64 if q % 2 == 0 else np.float32
+        T = int(rs.randint(100, 500)); K = int(rs.randint(2, 20)); W = int(rs.randint(3, 24)); F = int(rs.choice([1, 1, 3]))
+        D = rs.standard_normal((K, W) if F == 1 else (K, W, F)).astype(dt)
+        D = norm(D, axis=tuple(range(1, D.ndim)))
+        x = (0.05 * rs.standard_normal((T,) if F == 1 else (T, F))).astype(dt)
+        D3 = D.reshape((K, W, -1)); x2 = x.reshape((T, -1))
+        for _ in range(int(rs.randint(3, 12))):
+            k = rs.randint(0, K); t0 = rs.randint(0, T - W)
+            x2[t0:t0 + W] += (rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0]) * D3[k]).astype(dt)
+        kw = dict(nbBlocks=[1, 2, int(rs.randint(3, 9)), 'auto'][q % 4])
+        if q % 3 == 0:
+            kw['nbNonzeroCoefs'] = int(rs.randint(3, 15))
+        else:
+            kw['toleranceSnr'] = float(rs.uniform(5.0, 18.0))
+        if q % 5 == 0:
+            w = np.ones(K, dtype=dt); w[:K // 2] = 0.7
+            kw['weights'] = w
+        cases.append(('rand%02d_%s_T%d_K%d_W%d_F%d' % (q, 'f64' if dt == np.float64 else 'f32', T, K, W, F), x, D, kw))
     for name, x, D, kw in cases:
         coefficients, residual = ref.modeling.LoCOMP().computeCoefficients(x, D, **kw)
         names.append(name)
