@@ -96,6 +96,36 @@ def small_cases():
         D = norm(rs.standard_normal((6, 9)).astype(dt), axis=1)
         x = rs.standard_normal(40).astype(dt)
         cases.append(('%s_T40_K6_W9_L25' % tag, x, D, dict(nbNonzeroCoefs=25)))
+    # a random family from its own stream (appended: the cases above keep their inputs): short signals with even and
+    # odd widths whose pursuit keeps coming back to the borders (edge history, stale reflected sample of row T-1),
+    # planted + noisy mid-size signals, every selection mode
+    r2 = np.random.RandomState(20261004)
+    for q in range(64):
+        dt = np.float32 if q % 2 else np.float64
+        tag = 'f32' if dt == np.float32 else 'f64'
+        if q < 32:
+            W = int(r2.choice([2, 4, 6, 8, 3, 5])); K = int(r2.randint(1, 10)); T = int(r2.randint(3 * W, 12 * W + 10)); F = 1
+        else:
+            W = int(r2.randint(4, 24)); K = int(r2.randint(2, 24)); T = int(r2.randint(4 * W, 300)); F = int(r2.choice([1, 1, 3]))
+        D = r2.standard_normal((K, W) if F == 1 else (K, W, F)).astype(dt)
+        D = norm(D, axis=tuple(range(1, D.ndim)))
+        x = (0.05 * r2.standard_normal((T,) if F == 1 else (T, F))).astype(dt)
+        D3 = D.reshape((K, W, -1)); x2 = x.reshape((T, -1))
+        for _ in range(int(r2.randint(3, 10))):
+            k = r2.randint(0, K); t0 = int(r2.choice([0, T - W, r2.randint(0, T - W + 1)]))
+            x2[t0:t0 + W] += (r2.uniform(0.5, 2.0) * r2.choice([-1.0, 1.0]) * D3[k]).astype(dt)
+        kw = {}
+        mode = q % 4
+        if mode == 1 and T >= 8:
+            kw['nbBlocks'] = int(r2.randint(2, min(8, T // 3)))
+        elif mode == 2:
+            kw['nbBlocks'] = 'auto'
+        if q % 3 == 0:
+            kw['toleranceSnr'] = float(r2.uniform(8.0, 25.0)); kw['nbNonzeroCoefs'] = 40
+        else:
+            kw['nbNonzeroCoefs'] = int(r2.randint(5, 30))
+        name = 'rand%02d_%s_T%d_K%d_W%d_F%d' % (q, tag, T, K, W, F)
+        cases.append((name, x, D, kw))
     return cases
 
 
