@@ -704,6 +704,8 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             const int i = tid + u * kThreads;
             if (i < nsb) L.sbs[i] = os[u];
         }
+        // signals longer than 131072 samples have segments of 512+ positions: the rest of the touched segments
+        for (int i = tid + 2 * kThreads; i < nsb; i += kThreads) L.sbs[i] = Gs.bc[segbase + i];
 
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {

@@ -85,3 +85,34 @@ def test_non_converging_pursuit_raises_instead_of_growing_forever():
     x = np.ones((200, 2))
     with pytest.raises(HscmpError, match='does not converge'):
         ConvolutionalMatchingPursuit().computeCoefficients(x, np.stack([D, D], axis=2), nbNonzeroCoefs=6)
+
+
+def test_long_signals():
+    """A million samples on the MFMA path (segment maxima at their largest segment size), and a multi-feature input
+    longer than the row-bitmap / sparse-initial-correlation limit (262144 rows): generic initial correlation, sparse loop."""
+    rs = np.random.RandomState(17)
+    T = 1000003
+    D = rs.standard_normal((8, 16)).astype(np.float32)
+    D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
+    x = (0.01 * rs.standard_normal(T)).astype(np.float32)
+    for p in (0, 7, 500000, 999990, T - 1, T - 17, 123456):
+        k = rs.randint(0, 8); lo = p - 7; s, e = max(0, lo), min(T, lo + 16)
+        x[s:e] += (rs.uniform(1.0, 3.0) * D[k][s - lo:e - lo]).astype(np.float32)
+    _check(x, D, nbNonzeroCoefs=30)
+    _check(x, D, nbNonzeroCoefs=40, nbBlocks='auto')
+    _check(x, D, nbNonzeroCoefs=40, nbBlocks=8)                  # blocks of 125 000 samples: selection through the segment maxima
+    _check(x[:300001].astype(np.float64), D.astype(np.float64), nbNonzeroCoefs=25)
+    _check(x[:300001].astype(np.float64), D.astype(np.float64), nbNonzeroCoefs=25, nbBlocks=5)
+    T2, F = 300000, 4
+    D2 = np.zeros((6, 8, F))
+    for k in range(6):
+        for _ in range(3):
+            D2[k, rs.randint(0, 8), rs.randint(0, F)] = rs.uniform(0.5, 1.5)
+        D2[k] /= np.sqrt(np.sum(np.square(D2[k])))
+    S = np.zeros((F, 8, F)); S[np.arange(F), 3, np.arange(F)] = 1.0
+    D2 = np.concatenate((S, D2), axis=0)
+    x2 = np.zeros((T2, F))
+    for _ in range(400):
+        x2[rs.randint(0, T2), rs.randint(0, F)] = rs.uniform(0.5, 2.0)
+    x2[0, 1] = 1.5; x2[T2 - 1, 2] = -1.25
+    _check(x2, D2, nbNonzeroCoefs=120)
