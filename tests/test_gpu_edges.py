@@ -116,3 +116,30 @@ def test_long_signals():
         x2[rs.randint(0, T2), rs.randint(0, F)] = rs.uniform(0.5, 2.0)
     x2[0, 1] = 1.5; x2[T2 - 1, 2] = -1.25
     _check(x2, D2, nbNonzeroCoefs=120)
+
+
+BOUNDARY_SHAPES = [
+    # (T, K, W, F): around the dispatch thresholds -- MFMA image size (64 KB f32 / 128 KB f64), W <= 128, T >= 3W-2,
+    # 32- / 16-atom groups, segment size steps (T = 512 * 64, 512 * 128, 512 * 256)
+    (400, 255, 64, 1), (400, 256, 64, 1), (400, 257, 64, 1), (300, 512, 32, 1), (300, 1024, 16, 1), (700, 300, 64, 1),
+    (600, 33, 127, 1), (600, 33, 128, 1), (600, 33, 129, 1), (900, 9, 200, 1),
+    (3 * 40 - 3, 12, 40, 1), (3 * 40 - 2, 12, 40, 1), (3 * 40 - 1, 12, 40, 1), (3 * 41 - 3, 12, 41, 1), (3 * 41 - 2, 12, 41, 1),
+    (32768, 5, 8, 1), (32769, 5, 8, 1), (65536, 5, 8, 1), (65537, 5, 8, 1), (131072, 5, 8, 1), (131073, 5, 8, 1),
+    (500, 17, 9, 2), (500, 16, 9, 33), (260, 40, 5, 64),
+]
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('shape', BOUNDARY_SHAPES)
+def test_shapes_around_the_dispatch_thresholds(shape, dtype):
+    T, K, W, F = shape
+    rs = np.random.RandomState(T * 7 + K * 3 + W + F)
+    D = rs.standard_normal((K, W) if F == 1 else (K, W, F)).astype(dtype)
+    D /= np.sqrt(np.sum(np.square(D), axis=tuple(range(1, D.ndim)), keepdims=True))
+    x = (0.05 * rs.standard_normal((T,) if F == 1 else (T, F))).astype(dtype)
+    D3 = D.reshape((K, W, -1)); x2 = x.reshape((T, -1))
+    for p in (0, T - W, T // 2, T // 3):
+        if 0 <= p <= T - W:
+            x2[p:p + W] += (rs.uniform(0.8, 2.0) * D3[rs.randint(0, K)]).astype(dtype)
+    _check(x, D, nbNonzeroCoefs=14)
+    _check(x, D, nbNonzeroCoefs=14, nbBlocks=4)

@@ -204,7 +204,7 @@ def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed,
     from hsc_amd.dataset import MultilevelDictionaryGenerator, SignalGenerator
     from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
     rs = np.random.RandomState(500 + seed)
-    nlev = 2 + (seed % 2)
+    nlev = 2 + (seed % 3)
     scales = [int(rs.choice([8, 12, 16]))]
     for _ in range(nlev - 1):
         scales.append(scales[-1] * 2 + int(rs.randint(0, 5)))
