@@ -121,6 +121,20 @@ def test_random_configuration_vs_oracle(i):
         t2, k2, c2 = r2.events[0]
         assert np.array_equal(t2, t) and np.array_equal(k2, k) and np.array_equal(c2, c), tag
         assert np.array_equal(np.squeeze(r2.residuals[0]), np.squeeze(residual)) and r2.stop_reasons()[0] == info['stop'], tag
+    if i % 5 == 0:
+        # stopCondition served by one launch per round (hscmp_continue): stop after a few rounds, as the oracle's maxRounds
+        nrounds = 1 + i % 4
+        seen = []
+
+        def stop(sequence, residual_, coefficients_):
+            seen.append(1)
+            return len(seen) >= nrounds
+
+        cb = ConvolutionalMatchingPursuit()
+        cb.computeCoefficients(x, D, stopCondition=stop, **kw)
+        t3, k3, c3 = cb.lastResult.events[0]
+        coef3, res3, info3 = orc.cmp_encode(x, D, maxEvents=1 << 17, maxRounds=nrounds, **kw)
+        assert np.array_equal(t3, info3['t']) and np.array_equal(k3, info3['k']) and np.array_equal(c3, info3['c']), (tag, 'callback', nrounds)
 
 
 N_BATCHES = int(os.environ.get("HSCMP_FUZZ_BATCHES", "48"))
