@@ -143,3 +143,22 @@ def test_shapes_around_the_dispatch_thresholds(shape, dtype):
             x2[p:p + W] += (rs.uniform(0.8, 2.0) * D3[rs.randint(0, K)]).astype(dtype)
     _check(x, D, nbNonzeroCoefs=14)
     _check(x, D, nbNonzeroCoefs=14, nbBlocks=4)
+
+
+@pytest.mark.parametrize('xdt,ddt', [(np.float32, np.float64), (np.float64, np.float32), (np.int32, np.float64)])
+def test_mixed_input_dtypes(xdt, ddt):
+    """The compute dtype is numpy's result type of signal and dictionary, float32 only when both are float32
+    (modeling.py:1059-1067 converts nothing: numpy promotes inside the products)."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from oracle import hsc_oracle as orc
+    rs = np.random.RandomState(3)
+    D = rs.standard_normal((6, 12)).astype(ddt)
+    D /= np.sqrt(np.sum(np.square(D), axis=1, keepdims=True))
+    x = (rs.standard_normal(200) * 4).astype(xdt)
+    cmp = ConvolutionalMatchingPursuit()
+    coefficients, residual = cmp.computeCoefficients(x, D, nbNonzeroCoefs=10)
+    dt = np.float32 if (np.dtype(xdt) == np.float32 and np.dtype(ddt) == np.float32) else np.float64
+    coef, res, info = orc.cmp_encode(x.astype(dt), D.astype(dt), nbNonzeroCoefs=10)
+    t, k, c = cmp.lastResult.events[0]
+    assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c.astype(np.float64), info['c'].astype(np.float64))
+    assert (coefficients != coef).nnz == 0
