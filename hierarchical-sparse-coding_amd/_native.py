@@ -132,7 +132,7 @@ def nb_blocks_code(nbBlocks):
 def max_event_capacity(T):
     """Upper bound of the per-signal event lists: far beyond any converging pursuit (a signal of T samples is
     explained by at most a few atoms per sample), small enough that a non-terminating one fails fast."""
-    return max(1 << 16, 16 * int(T))
+    return max(1 << 18, 16 * int(T))
 
 
 def make_params(nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None, nbBlocks=1,
