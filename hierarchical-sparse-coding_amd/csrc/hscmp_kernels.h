@@ -484,6 +484,8 @@ template <typename R> struct GenericRecorr {
                                                         int, int, int&, R&) {}
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
     static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
+    static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, R,
+                                                           int, int, int, R&, R&) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -836,7 +838,8 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             int s, e, es;
             const int len = centered_span(T, W, p, s, e, es);
             R pb = (R)0, pa = (R)0;
-            {
+            // (a policy that knows which cells can be non-zero updates only those and returns its energy partials)
+            if (!Recorr::update_residual(P, S, G, A, plds, p, k, c, s, e, es, pb, pa)) {
                 const int n = len * F;
                 const R nc = -c;
                 const R* dk = S.D + ((int64_t)k * W + es) * F;

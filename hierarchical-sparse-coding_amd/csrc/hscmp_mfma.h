@@ -551,6 +551,8 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int TP = Tile::TP;
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const MfmaArgsT<R>&, char*) { return S.weights; }
     static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const MfmaArgsT<R>&, char*, int, int) {}
+    static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, R,
+                                                           int, int, int, R&, R&) { return false; }
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
 

@@ -571,6 +571,80 @@ template <typename R> struct SparseRecorr {
             }
         }
     }
+    // Residual subtraction with the local energies (modeling.py:996-1016) over the listed cells only.  The dense form
+    // streams the whole W x F window and the dense atom (96 KB per atom at BASELINE config 4: the loop's HBM traffic);
+    // here the span's listed non-zero cells are gathered, the atom's few non-zeros are applied to them (new cells
+    // start from 0), and the pinned energy order -- partial sum (i mod 256), each sequential in the cell index i --
+    // is kept by summing the cells in sorted order.  A zero cell adds +0 to its partial sum and an atom zero changes
+    // nothing, so the results are those of the dense form.  Returns false (nothing done) when a row list of the span
+    // has overflowed or the cells do not fit the LDS list: the dense form then runs.
+    static __device__ __forceinline__ bool update_residual(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A0, char* lds,
+                                                           int p, int k, R c, int s, int e, int es, R& pb, R& pa)
+    {
+        if (!A0.rl_cnt) return false;
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        const int T = P.T, F = P.F, tid = threadIdx.x, C = A.rl_cap, shift = __ffs(C) - 1;
+        const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
+        const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
+        int* key = L.key; R* before = L.val; R* after = L.rd; int* order = L.perm;
+        const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1];
+        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; }
+        __syncthreads();
+        // the span's listed cells (the atom's own cells were listed by on_atom: a new one still holds 0 and is skipped here)
+        const int items = (e - s) << shift;
+        for (int it = tid; it < items; it += kThreads) {
+            const int g = s + (it >> shift);
+            const int n = list_count(cnt + g);
+            if (n > C) { if ((it & (C - 1)) == 0) atomicAdd(&L.ctl[1], 1); continue; }
+            const int f = lf[((int64_t)g << shift) + (it & (C - 1))];
+            if (f < 0) continue;
+            const R v = G.r[(int64_t)g * F + f];
+            if (v != (R)0) {
+                const int o = atomicAdd(&L.ctl[0], 1);
+                if (o < L.caps.nz) { key[o] = (g - s) * F + f; before[o] = v; after[o] = v; }
+            }
+        }
+        __syncthreads();
+        const int n0 = L.ctl[0];
+        if (L.ctl[1] > 0 || n0 + (e1 - e0) > L.caps.nz) return false;                 // uniform
+        // the atom's non-zeros: -c*D[k] rounded, then += (utils.py:120,129)
+        const R nc = -c;
+        for (int q = e0 + tid; q < e1; q += kThreads) {
+            const int wf = A.nzwf[q], f = wf & 0xffff, g = p - P.off + (wf >> 16);
+            if (g < s || g >= e) continue;                                           // clipped part of the atom
+            const int i = (g - s) * F + f;
+            const R prod = nc * A.nzval[q];
+            int j = 0;
+            while (j < n0 && key[j] != i) ++j;
+            R vn;
+            if (j < n0) { vn = before[j] + prod; after[j] = vn; }
+            else {
+                vn = (R)0 + prod;
+                const int o = atomicAdd(&L.ctl[0], 1);
+                key[o] = i; before[o] = (R)0; after[o] = vn;
+            }
+            G.r[(int64_t)g * F + f] = vn;
+        }
+        __syncthreads();
+        const int n = L.ctl[0];
+        for (int j = tid; j < n; j += kThreads) {                                     // rank sort by cell index (distinct)
+            const int kj = key[j];
+            int rank = 0;
+            for (int q = 0; q < n; ++q) rank += (key[q] < kj) ? 1 : 0;
+            order[rank] = j;
+        }
+        __syncthreads();
+        for (int q = 0; q < n; ++q) {                                                 // partial sum tid, ascending cell index
+            const int j = order[q];
+            if ((key[j] & (kThreads - 1)) == tid) {
+                const R b = before[j], a = after[j];
+                const R sb = b * b, sa = a * a;
+                pb = pb + sb; pa = pa + sa;
+            }
+        }
+        return true;                                                                  // (pinned_tree2 of the caller synchronises)
+    }
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
                                                char* lds, int p, int k)
