@@ -486,6 +486,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
     static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, R,
                                                            int, int, int, R&, R&) { return false; }
+    static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const Args&, char*, int, int, R&) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -741,8 +742,11 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 } else {
                     // long windows (multi-feature inputs): the whole workgroup streams each window
                     for (int i = 0; i < n; ++i) {
-                        int len;
-                        const R e = block_window_energy(P, G, sh, ord_t[i], len);
+                        int len, ws, we, wes;
+                        len = centered_span(T, W, ord_t[i], ws, we, wes);
+                        R e = (R)0, q2 = (R)0;
+                        if (len > 0 && Recorr::window_partials(P, G, A, plds, ws, we, e)) pinned_tree2(e, q2, sh.red);   // listed cells only
+                        else e = block_window_energy(P, G, sh, ord_t[i], len);
                         if (tid == 0) {
                             const R mean = e / (R)((int64_t)len * F);
                             raw_t[i] = ((double)mean >= thr) ? 1 : 0;

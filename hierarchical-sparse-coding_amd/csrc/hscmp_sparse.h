@@ -645,6 +645,49 @@ template <typename R> struct SparseRecorr {
         }
         return true;                                                                  // (pinned_tree2 of the caller synchronises)
     }
+    // Energy partial sums of the clipped window [s, e) x F over its listed cells (weak-atom filter, :1090-1099), in the
+    // pinned order like update_residual.  Returns false when a row list of the window has overflowed or the cells
+    // do not fit: the dense form then runs.  All threads call it (barriers); p is this thread's partial sum.
+    static __device__ __forceinline__ bool window_partials(const DevParams& P, const Sig<R>& G, const Args& A0, char* lds, int s, int e, R& p)
+    {
+        if (!A0.rl_cnt) return false;
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        const int T = P.T, F = P.F, tid = threadIdx.x, C = A0.rl_cap, shift = __ffs(C) - 1;
+        const int* cnt = A0.rl_cnt + (int64_t)blockIdx.x * T;
+        const int* lf = A0.rl_f + (int64_t)blockIdx.x * T * C;
+        int* key = L.key; R* val = L.val; int* order = L.perm;
+        __syncthreads();                                                             // the lists of the previous window are consumed
+        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; }
+        __syncthreads();
+        const int items = (e - s) << shift;
+        for (int it = tid; it < items; it += kThreads) {
+            const int g = s + (it >> shift);
+            const int n = list_count(cnt + g);
+            if (n > C) { if ((it & (C - 1)) == 0) atomicAdd(&L.ctl[1], 1); continue; }
+            const int f = lf[((int64_t)g << shift) + (it & (C - 1))];
+            if (f < 0) continue;
+            const R v = G.r[(int64_t)g * F + f];
+            if (v != (R)0) {
+                const int o = atomicAdd(&L.ctl[0], 1);
+                if (o < L.caps.nz) { key[o] = (g - s) * F + f; val[o] = v; }
+            }
+        }
+        __syncthreads();
+        const int n = L.ctl[0];
+        if (L.ctl[1] > 0 || n > L.caps.nz) return false;                             // uniform
+        for (int j = tid; j < n; j += kThreads) {
+            const int kj = key[j];
+            int rank = 0;
+            for (int q = 0; q < n; ++q) rank += (key[q] < kj) ? 1 : 0;
+            order[rank] = j;
+        }
+        __syncthreads();
+        for (int q = 0; q < n; ++q) {
+            const int j = order[q];
+            if ((key[j] & (kThreads - 1)) == tid) { const R sq = val[j] * val[j]; p = p + sq; }
+        }
+        return true;
+    }
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
                                                char* lds, int p, int k)
