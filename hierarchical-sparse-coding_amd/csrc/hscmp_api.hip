@@ -444,7 +444,7 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
 
 // Slots of the previous level an input was scattered from (level chaining): the input then already sits in the
 // residual buffer and prepare only needs the energy.
-struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; };
+struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; bool lists; };
 
 template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, const void* x_dev, const ChainSource* chain = nullptr)
 {
@@ -452,7 +452,8 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (chain)
         hipLaunchKernelGGL((prepare_from_slots_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, chain->slot_t, chain->slot_k,
-                           chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc);
+                           chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc,
+                           chain->lists ? ctx->d_rl_cnt : nullptr, ctx->d_rl_f, kRowListCap);
     else
         hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -558,7 +559,7 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     ctx->rowflag_valid = true;                  // the sparse initial correlation skips its scan of the dense input
     ctx->rl_filled = lists;
     const ChainSource chain{prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
-                            has_min ? min_coefficients : 0.0};
+                            has_min ? min_coefficients : 0.0, lists};
     rc = run_encode<double>(ctx, P, ctx->d_resid, &chain);
     ctx->rowflag_valid = false; ctx->rl_filled = false;
     if (rc) return rc;

@@ -58,7 +58,8 @@ template <typename R>
 __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams P, State<R> S, const int* __restrict__ slot_t,
                                                                       const int* __restrict__ slot_k, const double* __restrict__ slot_a,
                                                                       const int* __restrict__ pstats, int pcap, int first, int has_min,
-                                                                      double minc)
+                                                                      double minc, const int* __restrict__ rl_cnt,
+                                                                      const int* __restrict__ rl_f, int rl_cap)
 {
     __shared__ R red[2 * kWaves];
     __shared__ int overflow;
@@ -84,7 +85,43 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
     if (over) atomicOr(&overflow, 1);
     __syncthreads();
     R p = (R)0, q = (R)0;
-    if (overflow) {
+    if (overflow && rl_cnt && rl_cap == 8) {
+        // too many cells per partial sum for the private lists: walk the per-row feature lists instead (rows ascending,
+        // features ascending inside a row = ascending cell index); every thread sees every listed cell and keeps its own
+        const int T = P.T, F = P.F, lane = tid & 63;
+        const int* cnt = rl_cnt + (int64_t)b * T;
+        const int* lf = rl_f + (int64_t)b * T * 8;
+        const R* r = S.residual + (int64_t)b * T * F;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int tl = t0 + lane;
+            const int nl = tl < T ? cnt[tl] : 0;
+            unsigned long long rows = __ballot(nl > 0);
+            while (rows) {                                   // uniform within the wave; all four waves do the same walk
+                const int q = __ffsll((long long)rows) - 1;
+                rows &= rows - 1ull;
+                const int t = t0 + q, n = __shfl(nl, q);
+                if (n > 8) {                                 // overflowed list: the row is dense
+                    for (int f = (int)(((unsigned)tid - (unsigned)((int64_t)t * F)) & (kThreads - 1)); f < F; f += kThreads) {
+                        const R v = r[(int64_t)t * F + f]; const R sq = v * v; p = p + sq;
+                    }
+                    continue;
+                }
+                int fs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int fv = lf[(int64_t)t * 8 + u]; fs[u] = fv < 0 ? INT_MAX : fv; }
+#pragma unroll
+                for (int a = 0; a < 8; ++a)                  // ascending features (tiny selection sort in registers)
+#pragma unroll
+                    for (int c2 = a + 1; c2 < 8; ++c2) if (fs[c2] < fs[a]) { const int tmp = fs[a]; fs[a] = fs[c2]; fs[c2] = tmp; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (fs[u] != INT_MAX && (int)(((int64_t)t * F + fs[u]) & (kThreads - 1)) == tid) {
+                        const R v = r[(int64_t)t * F + fs[u]]; const R sq = v * v; p = p + sq;
+                    }
+                }
+            }
+        }
+    } else if (overflow) {
         const int64_t total = (int64_t)P.T * P.F;
         const R* r = S.residual + (int64_t)b * total;
         for (int64_t i = tid; i < total; i += kThreads) { const R v = r[i]; const R sq = v * v; p = p + sq; }

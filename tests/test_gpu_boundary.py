@@ -132,3 +132,33 @@ def test_inputs_are_not_mutated():
     x0, D0 = x.copy(), D.copy()
     ConvolutionalMatchingPursuit().computeCoefficients(x, D, nbNonzeroCoefs=10)
     assert np.array_equal(x, x0) and np.array_equal(D, D0)
+
+
+def test_chained_level_energy_with_crowded_partial_sums():
+    """Level chaining takes the signal energy from the previous level's slots.  With more cells per pinned partial
+    sum than its private lists hold (here 30000 cells on 128 of the 256 partial sums) it walks the per-row feature
+    lists instead: the energy must still equal the oracle's pinned sum over the dense input, bit for bit."""
+    from hsc_amd import _native
+    from oracle import hsc_oracle as orc
+    rs = np.random.RandomState(8)
+    T = 30000
+    x = (rs.uniform(0.5, 2.0, size=T) * rs.choice([-1.0, 1.0], size=T)).astype(np.float32)
+    D0 = np.array([[1.0], [0.5]], dtype=np.float32)                 # one tap: every sample becomes one event of atom 0
+    e0 = _native.Engine(0); e0.set_dictionary(D0.reshape(2, 1, 1))
+    p0 = _native.make_params(nbNonzeroCoefs=T, eps=float(np.finfo(np.float32).eps), maxEvents=T + 8)
+    e0.encode_batch(x.reshape(1, T, 1), p0)
+    st = e0.fetch_stats()
+    assert st[0][_native.STAT_SLOTS] == T
+    D1 = np.zeros((3, 4, 2)); D1[0, 1, 0] = 1.0; D1[1, 1, 1] = 1.0; D1[2, 0, 0] = D1[2, 3, 0] = np.sqrt(0.5)
+    e1 = _native.Engine(0); e1.set_dictionary(D1, np.ones(3))
+    p1 = _native.make_params(nbNonzeroCoefs=5, eps=float(np.finfo(np.float32).eps), maxEvents=64)
+    e1.encode_batch_from_level(e0, 0, 1, 1e-16, p1)
+    assert e1.last_variant().startswith('dictlist_init+dictlist_loop')
+    dense = np.zeros((T, 2)); dense[:, 0] = x.astype(np.float64)     # what the scatter produced
+    energies = e1.fetch_energies()
+    assert energies[0][0] == orc.energy(dense.reshape(-1))
+    # and the pursuit that follows is the oracle's
+    coef, res, info = orc.cmp_encode(dense, D1, nbNonzeroCoefs=5, weights=np.ones(3))
+    ev = e1.fetch_events(); n = e1.fetch_stats()[0][_native.STAT_EVENTS]
+    assert np.array_equal(ev[0][0][:n], info['t']) and np.array_equal(ev[2][0][:n], info['c'])
+    e0.close(); e1.close()
