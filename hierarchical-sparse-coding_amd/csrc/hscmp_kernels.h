@@ -72,7 +72,9 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
     bool over = false;
     if (tid == 0) overflow = 0;
     __syncthreads();
-    for (int i = 0; i < n; ++i) {                   // (all threads read the same entries: broadcast loads)
+    const bool crowded = rl_cnt && rl_cap == 8 && n > 48 * kThreads;      // bound to overflow: go to the row lists at once
+    if (crowded && tid == 0) overflow = 1;
+    for (int i = 0; i < (crowded ? 0 : n); ++i) {   // (all threads read the same entries: broadcast loads)
         const double a = slot_a[(int64_t)src * pcap + i];
         if (a == 0.0 || (has_min && !(fabs(a) >= minc))) continue;
         const long long c = (long long)slot_t[(int64_t)src * pcap + i] * P.F + slot_k[(int64_t)src * pcap + i];
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
     R p = (R)0, q = (R)0;
     if (overflow && rl_cnt && rl_cap == 8) {
         // too many cells per partial sum for the private lists: walk the per-row feature lists instead (rows ascending,
-        // features ascending inside a row = ascending cell index); every thread sees every listed cell and keeps its own
+        // features ascending inside a row = ascending cell index).  Per batch of 64 rows every lane fetches ITS row's
+        // list and cell values (coalesced, independent loads), then the rows are replayed to all lanes with shuffles and
+        // each thread keeps the cells of its own partial sum; all four waves do the same walk.
         const int T = P.T, F = P.F, lane = tid & 63;
         const int* cnt = rl_cnt + (int64_t)b * T;
         const int* lf = rl_f + (int64_t)b * T * 8;
@@ -95,8 +99,22 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
         for (int t0 = 0; t0 < T; t0 += 64) {
             const int tl = t0 + lane;
             const int nl = tl < T ? cnt[tl] : 0;
+            int fs[8];
+            R vs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { fs[u] = INT_MAX; vs[u] = (R)0; }
+            if (nl > 0 && nl <= 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int fv = lf[(int64_t)tl * 8 + u]; fs[u] = fv < 0 ? INT_MAX : fv; }
+#pragma unroll
+                for (int a = 0; a < 8; ++a)                  // ascending features (selection sort in registers)
+#pragma unroll
+                    for (int c2 = a + 1; c2 < 8; ++c2) if (fs[c2] < fs[a]) { const int tmp = fs[a]; fs[a] = fs[c2]; fs[c2] = tmp; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (fs[u] != INT_MAX) vs[u] = r[(int64_t)tl * F + fs[u]];
+            }
             unsigned long long rows = __ballot(nl > 0);
-            while (rows) {                                   // uniform within the wave; all four waves do the same walk
+            while (rows) {                                   // uniform within the wave
                 const int q = __ffsll((long long)rows) - 1;
                 rows &= rows - 1ull;
                 const int t = t0 + q, n = __shfl(nl, q);
@@ -106,18 +124,11 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
                     }
                     continue;
                 }
-                int fs[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int fv = lf[(int64_t)t * 8 + u]; fs[u] = fv < 0 ? INT_MAX : fv; }
-#pragma unroll
-                for (int a = 0; a < 8; ++a)                  // ascending features (tiny selection sort in registers)
-#pragma unroll
-                    for (int c2 = a + 1; c2 < 8; ++c2) if (fs[c2] < fs[a]) { const int tmp = fs[a]; fs[a] = fs[c2]; fs[c2] = tmp; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (fs[u] != INT_MAX && (int)(((int64_t)t * F + fs[u]) & (kThreads - 1)) == tid) {
-                        const R v = r[(int64_t)t * F + fs[u]]; const R sq = v * v; p = p + sq;
-                    }
+                    const int f = __shfl(fs[u], q);
+                    const R v = __shfl(vs[u], q);
+                    if (f != INT_MAX && (int)(((int64_t)t * F + f) & (kThreads - 1)) == tid) { const R sq = v * v; p = p + sq; }
                 }
             }
         }
