@@ -56,6 +56,8 @@ struct hscmp_ctx {
     void* d_resid = nullptr; void* d_best_c = nullptr; int* d_best_k = nullptr;
     int* d_ev_t = nullptr; int* d_ev_k = nullptr; void* d_ev_c = nullptr;
     int* d_slot_t = nullptr; int* d_slot_k = nullptr; double* d_slot_a = nullptr;
+    unsigned long long* d_hkey = nullptr; int* d_hval = nullptr;   // slot hash table [B][hmask+1]
+    size_t cap_hkey = 0, cap_hval = 0;
     int* d_sel_t = nullptr; int* d_sel_k = nullptr; void* d_sel_c = nullptr;
     int* d_stats = nullptr; void* d_energy = nullptr; unsigned long long* d_edge = nullptr;
     DevParams P{};
@@ -119,7 +121,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 static void free_all(hscmp_ctx* c)
 {
     void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_Dc, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
-                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
+                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_hkey, c->d_hval, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -290,6 +292,9 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
     P.eps = p->eps;
     if (p->max_events <= 0) return fail(ctx, HSCMP_ERR_INVALID, "max_events must be > 0");
     P.cap = p->max_events;
+    P.hmask = slot_hash_mask(P.cap);
+    P.hash_min = kSlotHashMin;
+    if (const char* v = getenv("HSCMP_SLOT_HASH_MIN")) P.hash_min = std::max(0, atoi(v));
     P.max_rounds = p->max_rounds;
     *out = P;
     return HSCMP_OK;
@@ -338,6 +343,8 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, ctx->F > 1 ? B * T : 0},
         {(void**)&ctx->d_rl_cnt, &ctx->cap_rl_cnt, use_row_lists(ctx) ? B * T * sizeof(int) : 0},
         {(void**)&ctx->d_rl_f, &ctx->cap_rl_f, use_row_lists(ctx) ? B * T * kRowListCap * sizeof(int) : 0},
+        {(void**)&ctx->d_hkey, &ctx->cap_hkey, B * ((size_t)P.hmask + 1) * sizeof(unsigned long long)},
+        {(void**)&ctx->d_hval, &ctx->cap_hval, B * ((size_t)P.hmask + 1) * sizeof(int)},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -359,6 +366,7 @@ template <typename R> static State<R> make_state(hscmp_ctx* c)
     S.residual = (R*)c->d_resid; S.best_c = (R*)c->d_best_c; S.best_k = c->d_best_k;
     S.ev_t = c->d_ev_t; S.ev_k = c->d_ev_k; S.ev_c = (R*)c->d_ev_c;
     S.slot_t = c->d_slot_t; S.slot_k = c->d_slot_k; S.slot_a = c->d_slot_a;
+    S.hkey = c->d_hkey; S.hval = c->d_hval;
     S.sel_t = c->d_sel_t; S.sel_k = c->d_sel_k; S.sel_c = (R*)c->d_sel_c;
     S.stats = c->d_stats; S.energy = (R*)c->d_energy; S.edge = c->d_edge;
     return S;
@@ -624,7 +632,19 @@ extern "C" int hscmp_grow_events(hscmp_ctx* ctx, int new_max_events)
     for (size_t b = 0; b < B; ++b)
         if (stats[b * ST_COUNT + ST_STOP] == STOP_CAPACITY) stats[b * ST_COUNT + ST_STOP] = STOP_RUNNING;
     HIP_TRY(ctx, hipMemcpy(ctx->d_stats, stats.data(), stats.size() * sizeof(int), hipMemcpyHostToDevice));
-    ctx->cap = new_max_events; ctx->P.cap = new_max_events; ctx->last.max_events = new_max_events;
+    // the slot hash table follows the capacity; the loop rebuilds its contents from the slot list on the next launch
+    const unsigned hmask = slot_hash_mask(new_max_events);
+    struct Tab { void** p; size_t* cap; size_t elem; };
+    Tab tabs[] = {{(void**)&ctx->d_hkey, &ctx->cap_hkey, sizeof(unsigned long long)}, {(void**)&ctx->d_hval, &ctx->cap_hval, sizeof(int)}};
+    for (const Tab& t : tabs) {
+        const size_t bytes = B * ((size_t)hmask + 1) * t.elem;
+        if (*t.p && *t.cap >= bytes) continue;
+        if (*t.p) { (void)hipFree(*t.p); *t.p = nullptr; *t.cap = 0; }
+        hipError_t e = hipMalloc(t.p, bytes);
+        if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        *t.cap = bytes;
+    }
+    ctx->cap = new_max_events; ctx->P.cap = new_max_events; ctx->P.hmask = hmask; ctx->last.max_events = new_max_events;
     return HSCMP_OK;
 }
 

@@ -64,9 +64,19 @@ struct DevParams {
     double thres;       // nullCoeffThres
     double eps;
     int cap;            // max events per signal
+    int hash_min;       // slot count from which the loop keeps that table (kSlotHashMin; HSCMP_SLOT_HASH_MIN overrides)
+    unsigned hmask;     // slots of the per-signal (t,k) -> coefficient-slot hash table, minus one (power of two >= 2*cap)
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
 };
+
+// table size of the slot hash: load factor <= 1/2 whatever the event list holds
+inline unsigned slot_hash_mask(int cap)
+{
+    unsigned h = 64;
+    while (h < 2u * (unsigned)cap) h <<= 1;
+    return h - 1;
+}
 
 // segment size: the smallest power of two >= 64 that keeps the segment count within maxseg
 inline void set_segments(DevParams& P, int maxseg)
@@ -92,6 +102,7 @@ template <typename R> struct State {
     int* best_k;        // [B][T]
     int* ev_t; int* ev_k; R* ev_c;            // [B][cap]
     int* slot_t; int* slot_k; double* slot_a; // [B][cap]
+    unsigned long long* hkey; int* hval;      // [B][hmask+1] open-addressing table over the slots (built by the loop once a signal has many)
     int* sel_t; int* sel_k; R* sel_c;         // [B][2*maxsel]  (two halves: raw / ordered)
     int* stats;         // [B][ST_COUNT]
     R* energy;          // [B][2]: signal, residual

@@ -352,6 +352,8 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     // control block (written by thread 0, read by all after a barrier)
     int nsel, converged, stop, found, skip;
     int nullsel;              // a fused atom body found the selected coefficient null (:974): the round selected nothing
+    int hashed;               // the signal's slot hash table is built and answers the duplicate lookups (see slot_find)
+    unsigned fpos;            // single arg-max rounds: where slot_find stopped (the free entry a new slot takes)
     int nnz, ndup, rounds, iters, nev, nslots, offset;
     int atom_t, atom_k;
     R atom_c;
@@ -362,8 +364,68 @@ template <typename R> struct Sig {   // per-signal views
     R* r; R* bc; int* bk;
     int* ev_t; int* ev_k; R* ev_c;
     int* slot_t; int* slot_k; double* slot_a;
+    unsigned long long* hkey; int* hval;
     int* sel_t; int* sel_k; R* sel_c;
 };
+
+// ------------------------------------------------------------------------------------------------
+// (t,k) -> coefficient slot (:1106-1114 looks the pair up in the dict of coefficients).  Short slot lists are
+// searched directly behind a Bloom filter in LDS; from kSlotHashMin slots on the filter saturates and every atom
+// would pay for a scan of the whole list, so the workgroup builds an open-addressing table in global memory
+// (linear probing, load <= 1/2) and keeps it current.  All table accesses are agent-scope atomics (L2): the
+// compare-and-swap inserts and the probing loads then see the same copy whatever the vector cache holds.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSlotHashMin = 1024;
+constexpr unsigned long long kSlotEmpty = ~0ull;
+__device__ __forceinline__ unsigned long long slot_key(int t, int k) { return ((unsigned long long)(unsigned)t << 32) | (unsigned)k; }
+__device__ __forceinline__ unsigned slot_hash(unsigned long long key)
+{
+    key *= 0x9E3779B97F4A7C15ull;
+    return (unsigned)(key >> 32);
+}
+__device__ __forceinline__ unsigned long long hkey_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hkey_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int hval_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hval_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// slot of (t,k) or -1; pos = the entry that holds it / the free entry the probe ended on (one thread)
+template <typename R> __device__ __forceinline__ int slot_find(const Sig<R>& G, unsigned hmask, int t, int k, unsigned& pos)
+{
+    const unsigned long long key = slot_key(t, k);
+    unsigned h = slot_hash(key) & hmask;
+    for (;;) {
+        const unsigned long long q = hkey_load(G.hkey + h);
+        if (q == key) { pos = h; return hval_load(G.hval + h); }
+        if (q == kSlotEmpty) { pos = h; return -1; }
+        h = (h + 1) & hmask;
+    }
+}
+// (t,k) is not in the table: enter it (any number of threads at once)
+template <typename R> __device__ __forceinline__ void slot_insert(const Sig<R>& G, unsigned hmask, int t, int k, int si)
+{
+    const unsigned long long key = slot_key(t, k);
+    unsigned h = slot_hash(key) & hmask;
+    for (;;) {
+        unsigned long long expect = kSlotEmpty;
+        if (__hip_atomic_compare_exchange_strong(G.hkey + h, &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        h = (h + 1) & hmask;
+    }
+    hval_store(G.hval + h, si);
+}
+// the entry `pos` is free (slot_find ended there and nothing was entered since): one store, nobody waits
+template <typename R> __device__ __forceinline__ void slot_insert_at(const Sig<R>& G, unsigned pos, int t, int k, int si)
+{
+    hval_store(G.hval + pos, si);
+    hkey_store(G.hkey + pos, slot_key(t, k));
+}
+// table of the first `nslots` slots, by the whole workgroup (the slot list must be visible: call after a full
+// barrier; the caller ends with one as well)
+template <typename R> __device__ __forceinline__ void slot_table_build(const Sig<R>& G, unsigned hmask, int nslots)
+{
+    for (unsigned i = threadIdx.x; i <= hmask; i += kThreads) hkey_store(G.hkey + i, kSlotEmpty);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nslots; i += kThreads) slot_insert(G, hmask, G.slot_t[i], G.slot_k[i], i);
+}
 
 // arg-max of the per-position best over positions [t0,t1) by one wave; result in all lanes.
 // SO (score-only policy): G.bc[t] already IS the score max_k |c[t,k]*w_k|.
@@ -638,6 +700,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     G.bk = S.best_k + (int64_t)b * T;
     G.ev_t = S.ev_t + (int64_t)b * P.cap; G.ev_k = S.ev_k + (int64_t)b * P.cap; G.ev_c = S.ev_c + (int64_t)b * P.cap;
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
+    G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
@@ -657,7 +720,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     if (tid == 0) {
         sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
-        sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1; sh.nullsel = 0;
+        sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1; sh.nullsel = 0; sh.hashed = 0; sh.fpos = 0;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
     }
     if constexpr (!Recorr::kFused) {
@@ -824,13 +887,34 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         // A round whose atoms do not all fit the event list is not started: the state then is exactly that
         // of a round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
         const bool lists_full = sh.nev + nsel > P.cap;  // uniform (LDS values after a barrier)
-        // every thread has read the event count before thread 0 advances it (the step-by-step body may reach
-        // its bookkeeping without passing another barrier; the fused bodies pass several first)
+        // the slot list has outgrown the Bloom filter: duplicate lookups go through the hash table from here on
+        const bool build_table = !sh.hashed && sh.nslots >= P.hash_min;
+        const bool hashed = sh.hashed || build_table;
+        // every thread has read the event / slot counts before thread 0 advances them (the step-by-step body may
+        // reach its bookkeeping without passing another barrier; the fused bodies pass several first)
         if constexpr (!Recorr::kFused) __syncthreads();
         if (lists_full) {
             __syncthreads();
             if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
             break;
+        }
+        if (build_table) {
+            __syncthreads();                         // (drains the deferred slot stores of the fused bodies)
+            slot_table_build(G, P.hmask, sh.nslots);
+            if (tid == 0) sh.hashed = 1;
+            __syncthreads();
+        }
+        if constexpr (!Recorr::kFused) {
+            // The pairs of one round are distinct (one per block), so the table as of the round start answers for all
+            // of them: one lookup per atom, side by side.  raw_t (free after the selection) carries the answers.
+            if (hashed && nsel > 0) {
+                if (!P.blocked) {
+                    if (tid == 0) { unsigned pos; sh.found = slot_find(G, P.hmask, p_sel, k_sel, pos); sh.fpos = pos; }
+                } else {
+                    for (int i = tid; i < nsel; i += kThreads) { unsigned pos; raw_t[i] = slot_find(G, P.hmask, ord_t[i], ord_k[i], pos); }
+                    __syncthreads();
+                }
+            }
         }
         // =========================== apply the selected atoms (:1101-1142) ===========================
         bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
@@ -848,7 +932,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             // ---- :1106-1114 duplicate / nnz bookkeeping, coefficient accumulation, event append
             // the slot list is searched only when the Bloom filter says the pair may own a slot already
             const unsigned hb = bloom_hash(p, k);
-            const bool maybe_dup = ((sh.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;     // uniform (LDS, ordered by the barriers below)
+            const bool maybe_dup = !hashed && ((sh.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;    // uniform (LDS, ordered by the barriers below)
             if (maybe_dup) {
                 if (tid == 0) sh.found = -1;
                 __syncthreads();
@@ -861,11 +945,16 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if (tid == 0) {
                 if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
                 else {
-                    int si = maybe_dup ? sh.found : -1;
+                    int si = hashed ? (P.blocked ? raw_t[ai] : sh.found) : (maybe_dup ? sh.found : -1);
                     if (si >= 0 && fabs(G.slot_a[si]) > 0.0) sh.ndup += 1;
                     else if (rabs(c) > (R)0) sh.nnz += 1;
                     if (si < 0) {
                         si = sh.nslots++; G.slot_t[si] = p; G.slot_k[si] = k; new_slot = true;
+                        if (hashed) {
+                            // one atom per round: the probe's free entry is still free.  Blocked rounds enter their
+                            // new slots together at the round end (raw_t <= -2 names the slot).
+                            if (!P.blocked) slot_insert_at(G, sh.fpos, p, k, si); else raw_t[ai] = -2 - si;
+                        }
                         G.slot_a[si] = 0.0 + (double)c;                 // (:992 starts the accumulator at 0.0)
                     } else {
                         G.slot_a[si] += (double)c;
@@ -879,7 +968,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             lds_barrier();
             // the filter is updated only now: every thread has read this atom's bit (maybe_dup) before the barrier
             // above, and the next read comes after the barriers of the residual update
-            if (new_slot) sh.bloom[hb >> 5] |= 1u << (hb & 31);
+            if (new_slot && !hashed) sh.bloom[hb >> 5] |= 1u << (hb & 31);
             if (sh.skip) break;
             if constexpr (!Recorr::kFused) HSCMP_STAMP(33);
 
@@ -960,6 +1049,14 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if (sh.converged) break;
         }
 
+        if constexpr (!Recorr::kFused) {
+            // blocked rounds: the new slots of the round enter the table (thread 0's notes are behind the atoms' barriers)
+            if (hashed && P.blocked)
+                for (int i = tid; i < nsel; i += kThreads) {
+                    const int v = raw_t[i];
+                    if (v <= -2) slot_insert(G, P.hmask, ord_t[i], ord_k[i], -2 - v);
+                }
+        }
         // =========================== slow stop rules (:1145-1163) ===========================
         if constexpr (Recorr::kFused) {
             // single arg-max rounds without a residual-scale rule need no further synchronisation:

@@ -739,13 +739,21 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         }
 
         // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
+        // Long slot lists (sh.hashed, see slot_find): the bookkeeping thread probes the hash table instead; its
+        // first probe is in flight under the atom's work and is only looked at in the bookkeeping below.
+        const bool hashed = sh.hashed != 0;                     // uniform: published before a full barrier
         const unsigned hb = bloom_hash(p, k);
-        const bool maybe_dup = ((L.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;      // uniform
+        const bool maybe_dup = !hashed && ((L.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;      // uniform
+        unsigned long long probe_key = kSlotEmpty;
+        unsigned probe_pos = 0;
         if (maybe_dup) {
             __syncthreads();                                    // drains the bookkeeper's deferred slot stores
             const int nslots = sh.nslots;
             for (int i = tid; i < nslots; i += kThreads)
                 if (Gs.slot_t[i] == p && Gs.slot_k[i] == k) sh.found = i;      // at most one match
+        } else if (hashed && tid == kBook) {
+            probe_pos = slot_hash(slot_key(p, k)) & P.hmask;
+            probe_key = hkey_load(Gs.hkey + probe_pos);
         }
 
         // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
@@ -832,12 +840,22 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             const R e_before = b01 + b23, e_after = a01 + a23;
             const R loss = e_before - e_after;              // :1005
             sh.e_res = sh.e_res - loss;                         // :1014
-            si = sh.found;
-            sh.found = -1;
+            if (hashed) {
+                const unsigned long long key = slot_key(p, k);
+                for (;;) {                                      // the rest of the linear probe (usually none)
+                    if (probe_key == key) { si = hval_load(Gs.hval + probe_pos); break; }
+                    if (probe_key == kSlotEmpty) break;
+                    probe_pos = (probe_pos + 1) & P.hmask;
+                    probe_key = hkey_load(Gs.hkey + probe_pos);
+                }
+            } else {
+                si = sh.found;
+                sh.found = -1;
+            }
             if (si >= 0) { acc_old = Gs.slot_a[si]; }           // rare: re-selection of an existing (t,k)
             if (si >= 0 && fabs(acc_old) > 0.0) sh.ndup += 1;
             else if (rabs(c) > (R)0) sh.nnz += 1;
-            if (si < 0) { new_slot = true; si = sh.nslots++; L.bloom[hb >> 5] |= 1u << (hb & 31); }
+            if (si < 0) { new_slot = true; si = sh.nslots++; if (!hashed) L.bloom[hb >> 5] |= 1u << (hb & 31); }
             ev = sh.nev++;
             sh.iters += 1;
             // rows lo..hi now carry reflect-padded values (see edge_window_value)
@@ -858,7 +876,10 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         if (tid == kBook) {
             // deferred global stores of the bookkeeping: nobody waits for them (the duplicate scan
             // re-synchronises before it reads the slot list), they retire under the next atom's MFMAs
-            if (new_slot) { Gs.slot_t[si] = p; Gs.slot_k[si] = k; }
+            if (new_slot) {
+                Gs.slot_t[si] = p; Gs.slot_k[si] = k;
+                if (hashed) slot_insert_at(Gs, probe_pos, p, k, si);            // the probe's free entry
+            }
             Gs.slot_a[si] = acc_old + (double)c;                // :1114, :992  (0.0 + c for a new slot)
             Gs.ev_t[ev] = p; Gs.ev_k[ev] = k; Gs.ev_c[ev] = c;
         }

@@ -192,7 +192,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             K = eng.K
             out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
             tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
-                      selections=int(stats[:, _native.STAT_ITERATIONS].sum()))
+                      selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()))
             return out, tm
 
         per_level = [[None] * B for _ in range(nbLevels)]
@@ -226,11 +226,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     Dl, wl = setups[l][0], setups[l][1]
                     engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
                     fmax = max(fmax, Dl.shape[2])
-                    timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, chunks=0))
+                    timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, chunks=0))
                 if memoryBudget is None:
                     memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
                 # per signal on the device: the dense float64 residual [T, F] (the input is scattered straight into it) + per-row state
-                chunk = int(max(1, min(B, memoryBudget // (1.05 * T * fmax * 8 + 128 * T))))
+                chunk = int(max(1, min(B, memoryBudget // (1.05 * T * fmax * 8 + 160 * T))))
                 for first in range(0, B if nbLevels > 1 else 0, chunk):
                     count = min(chunk, B - first)
                     for l in range(1, nbLevels):
@@ -242,7 +242,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                                               count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64))
                         per_level[l][first:first + count] = coefs
                         acc = timings[l]
-                        acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['chunks'] += 1
+                        acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['chunks'] += 1
                         acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
         # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
         # kernels it spends its time in release the interpreter lock

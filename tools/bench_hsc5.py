@@ -25,4 +25,4 @@ for rep in range(2):
 snr = 10 * np.log10(np.sum(xs.astype(np.float64) ** 2) / np.sum(residuals ** 2))
 print('B=%d T=%d wall %.2f s  SNR %.1f dB  nnz/level %s' % (B, T, wall, snr, [int(np.mean([c[l].nnz for c in coefs])) for l in range(3)]))
 for tm in timings:
-    print('  level %d: %-32s init %.2f ms  loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
+    print('  level %d: %-32s init %.2f ms  loop %.2f ms  selections %d (%d re-selections)' % (tm['level'], tm['variant'], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections'], tm.get('duplicates', 0)))
