@@ -336,6 +336,8 @@ __device__ __forceinline__ unsigned bloom_hash(int t, int k)
     return h & (kBloomWords * 32 - 1);
 }
 
+constexpr int kSelLds = 16;               // rounds of at most this many candidates keep their selection lists in LDS
+
 template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> struct IterSharedT {
     unsigned bloom[WITH_CK ? kBloomWords : 1];    // step-by-step atom body: (t,k) pairs that own a slot (fused policies keep their own)
     R seg_score[MAXSEG];
@@ -347,6 +349,8 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     R part_c[WITH_PART ? kThreads : 1];
     int part_k[WITH_PART ? kThreads : 1];
     R red[2 * kWaves];
+    // blocked selection (:908-962): raw / ordered candidate lists of a round (longer lists live in State::sel_*)
+    int sel_t[2 * kSelLds]; int sel_k[2 * kSelLds]; R sel_c[2 * kSelLds];
     Cand<R> cred[kWaves];
     int wtot[kWaves];
     // control block (written by thread 0, read by all after a barrier)
@@ -597,6 +601,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, R,
                                                            int, int, int, R&, R&) { return false; }
     static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const Args&, char*, int, int, R&) { return false; }
+    static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const Args&, char*, int, int, int, int, R&) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -735,8 +740,12 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
     }
     __syncthreads();
 
-    int* raw_t = G.sel_t; int* raw_k = G.sel_k; R* raw_c = G.sel_c;                       // first half
-    int* ord_t = G.sel_t + P.maxsel; int* ord_k = G.sel_k + P.maxsel; R* ord_c = G.sel_c + P.maxsel; // second half
+    // candidate lists of a round: LDS when they fit (the compactions and sorts of the blocked selection are a chain
+    // of dependent passes over them), else the per-signal global buffers; the select-only entry point hands the
+    // ordered list back through the global buffer
+    const bool sel_lds = P.maxsel <= kSelLds && !P.select_only;
+    int* raw_t = sel_lds ? sh.sel_t : G.sel_t; int* raw_k = sel_lds ? sh.sel_k : G.sel_k; R* raw_c = sel_lds ? sh.sel_c : G.sel_c;   // first half
+    int* ord_t = raw_t + P.maxsel; int* ord_k = raw_k + P.maxsel; R* ord_c = raw_c + P.maxsel;                                      // second half
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
 
@@ -808,6 +817,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 if (lane == 0) { raw_t[j] = valid ? win.i : -1; raw_k[j] = wk; raw_c[j] = wc; }
             }
             __syncthreads();
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(48);
             // :946-948 drop null coefficients (and invalid blocks): raw -> ord
             int n = block_compact(nb, [&](int i) { return raw_t[i] >= 0 && (!has_thres || fabs((double)raw_c[i]) > thres); },
                                   raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh);
@@ -836,6 +846,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 ord_t[rank] = raw_t[i]; ord_k[rank] = raw_k[i]; ord_c[rank] = raw_c[i];
             }
             __syncthreads();
+            if constexpr (!Recorr::kFused) HSCMP_STAMP(49);
             // :1090-1099 weak-atom filter
             if (P.has_snr && n > 1) {
                 const R tol_energy = sh.e_sig / (R)P.snr_ratio;
@@ -851,8 +862,22 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                         }
                     }
                 } else {
-                    // long windows (multi-feature inputs): the whole workgroup streams each window
+                    // long windows (multi-feature inputs).  A policy that knows which cells can be non-zero gives every
+                    // wave its own candidates first (flag -1: not settled that way) ...
+                    for (int i = wv; i < n; i += kWaves) {
+                        int len, ws, we, wes;
+                        len = centered_span(T, W, ord_t[i], ws, we, wes);
+                        R e = (R)0;
+                        const bool done = len > 0 && Recorr::wave_window_listed(P, G, A, plds, ws, we, lane, wv, e);
+                        if (lane == 0) {
+                            const R mean = e / (R)((int64_t)len * F);
+                            raw_t[i] = !done ? -1 : ((double)mean >= thr) ? 1 : 0;
+                        }
+                    }
+                    __syncthreads();
+                    // ... and the whole workgroup streams what is left, window by window
                     for (int i = 0; i < n; ++i) {
+                        if (raw_t[i] >= 0) continue;                       // uniform
                         int len, ws, we, wes;
                         len = centered_span(T, W, ord_t[i], ws, we, wes);
                         R e = (R)0, q2 = (R)0;

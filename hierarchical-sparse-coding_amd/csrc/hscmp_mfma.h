@@ -554,6 +554,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, R,
                                                            int, int, int, R&, R&) { return false; }
     static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, R&) { return false; }
+    static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, int, int, R&) { return false; }
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
 

@@ -142,7 +142,9 @@ template <typename R> struct SparseLds {
 
 __host__ __device__ inline size_t sparse_lds_bytes_of(const SparseCaps& c, size_t es)
 {
-    const size_t b = 16 + (size_t)c.nz * (es + 4) + (size_t)(c.rows + 1) * 8 + 8 + (size_t)c.rec * (8 + 3 * es + 8);
+    size_t b = 16 + (size_t)c.nz * (es + 4) + (size_t)(c.rows + 1) * 8 + 8 + (size_t)c.rec * (8 + 3 * es + 8);
+    const size_t wave_energy = (size_t)kWaves * kThreads * (2 * es + 4);     // SparseRecorr::wave_window_listed borrows the region
+    if (b < wave_energy) b = wave_energy;
     return (b + 15) / 16 * 16;
 }
 template <typename R> __host__ __device__ inline size_t sparse_lds_bytes(const SparseCaps& c) { return sparse_lds_bytes_of(c, sizeof(R)); }
@@ -296,6 +298,9 @@ __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G
     return L.ctl[0];
 }
 
+__device__ __forceinline__ unsigned long long score_bits(double s) { return (unsigned long long)__double_as_longlong(s); }
+__device__ __forceinline__ unsigned long long score_bits(float s) { return (unsigned long long)__float_as_uint(s); }
+
 // Rows [row0, row0+nrows) x all atoms -> per-position best (best_c, best_k), sparsity aware.
 //   nrows <= 2W-1 (table capacity).  All threads of the workgroup call it (contains barriers).
 template <typename R>
@@ -405,25 +410,72 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             }
             __syncthreads();
             HSCMP_STAMP(43);
-            //  d. per-row best over atoms, one thread per row: the listed outputs (ascending k inside a row) against
-            //     the zeros of all the others -- a zero score never beats k = 0, the first of the ties
-            for (int row = tid; row < nrows; row += kThreads) {
-                const int t = row0 + row;
-                if (t < 0 || t >= T) continue;                       // overlapReplace clipping (utils.py:133-161)
-                const int b0 = bucketed ? start[row] : 0, b1 = bucketed ? start[row + 1] : m;
-                R bs = (R)0, c = (R)0;
-                int k = 0;
-                for (int sp = b0; sp < b1; ++sp) {
+            //  d. per-row best over atoms: the listed outputs against the zeros of all the others -- a zero score never
+            //     beats k = 0, the first of the ties; among equal scores the lowest atom wins (np.argmax).
+            if (nrows <= reccap) {
+                // all listed outputs side by side: row maximum of the score bits (scores are >= 0, so their bit
+                // patterns order like the values), then the lowest atom that reaches it, then its coefficient.
+                // The per-row cells take the place of the factor / key arrays, which are dead after step c.
+                unsigned long long* rmax = L.rkey;
+                int* rk = L.perm;
+                R* c0 = L.rx; R* rc = L.rd;
+                for (int row = tid; row < nrows; row += kThreads) { rmax[row] = 0ull; rk[row] = INT_MAX; c0[row] = (R)0; }
+                __syncthreads();
+                for (int sp = tid; sp < m; sp += kThreads) {
                     const unsigned ok = L.okey[sp];
-                    if (ok == ~0u || (int)(ok >> 16) != row) continue;
-                    const int kk = (int)(ok & 0xffffu);
+                    if (ok == ~0u) continue;
+                    const int row = (int)(ok >> 16), kk = (int)(ok & 0xffffu);
                     const R o = L.out[sp];
-                    if (kk == 0) c = o;                              // the value of the default winner
+                    if (kk == 0) c0[row] = o;                            // the value of the default winner
                     const R sc = score_of(o, kk, A.wts);
-                    if (sc > bs) { bs = sc; k = kk; c = o; }
+                    if (sc > (R)0) atomicMax(&rmax[row], score_bits(sc));
                 }
-                G.bc[t] = c; G.bk[t] = k;
+                __syncthreads();
+                for (int sp = tid; sp < m; sp += kThreads) {
+                    const unsigned ok = L.okey[sp];
+                    if (ok == ~0u) continue;
+                    const int row = (int)(ok >> 16), kk = (int)(ok & 0xffffu);
+                    const R sc = score_of(L.out[sp], kk, A.wts);
+                    if (sc > (R)0 && score_bits(sc) == rmax[row]) atomicMin(&rk[row], kk);
+                }
+                __syncthreads();
+                for (int sp = tid; sp < m; sp += kThreads) {
+                    const unsigned ok = L.okey[sp];
+                    if (ok == ~0u) continue;
+                    const int row = (int)(ok >> 16), kk = (int)(ok & 0xffffu);
+                    const R o = L.out[sp];
+                    const R sc = score_of(o, kk, A.wts);
+                    if (sc > (R)0 && score_bits(sc) == rmax[row] && kk == rk[row]) rc[row] = o;
+                }
+                __syncthreads();
+                for (int row = tid; row < nrows; row += kThreads) {
+                    const int t = row0 + row;
+                    if (t < 0 || t >= T) continue;                       // overlapReplace clipping (utils.py:133-161)
+                    const int k = rk[row];
+                    if (k == INT_MAX) { G.bc[t] = c0[row]; G.bk[t] = 0; }
+                    else { G.bc[t] = rc[row]; G.bk[t] = k; }
+                }
+            } else {
+                // (more rows than list entries: one thread per row walks its bucket, ascending k inside a row)
+                for (int row = tid; row < nrows; row += kThreads) {
+                    const int t = row0 + row;
+                    if (t < 0 || t >= T) continue;
+                    const int b0 = bucketed ? start[row] : 0, b1 = bucketed ? start[row + 1] : m;
+                    R bs = (R)0, c = (R)0;
+                    int k = 0;
+                    for (int sp = b0; sp < b1; ++sp) {
+                        const unsigned ok = L.okey[sp];
+                        if (ok == ~0u || (int)(ok >> 16) != row) continue;
+                        const int kk = (int)(ok & 0xffffu);
+                        const R o = L.out[sp];
+                        if (kk == 0) c = o;
+                        const R sc = score_of(o, kk, A.wts);
+                        if (sc > bs) { bs = sc; k = kk; c = o; }
+                    }
+                    G.bc[t] = c; G.bk[t] = k;
+                }
             }
+            HSCMP_STAMP(51);
             __syncthreads();
             HSCMP_STAMP(44);
             return;
@@ -686,6 +738,64 @@ template <typename R> struct SparseRecorr {
             const int j = order[q];
             if ((key[j] & (kThreads - 1)) == tid) { const R sq = val[j] * val[j]; p = p + sq; }
         }
+        return true;
+    }
+    // The same energy by ONE wave, without workgroup barriers (the weak-atom filter gives every wave its own
+    // candidates): lane = row of the window; its listed cells go to the slot of their partial sum i mod 256 in the
+    // wave's LDS table.  A partial sum with one or two cells is order free (0 + a = a, a + b = b + a); a window with
+    // three cells in one partial sum, or with an overflowed row list, is left to window_partials (returns false,
+    // wave-uniform).  The tree is that of wave_window_energy.  Result in lane 0.
+    static __device__ __forceinline__ bool wave_window_listed(const DevParams& P, const Sig<R>& G, const Args& A0, char* lds,
+                                                              int s, int e, int lane, int wv, R& out)
+    {
+        if (!A0.rl_cnt || A0.rl_cap != 8) return false;
+        const int T = P.T, F = P.F;
+        const int* cnt = A0.rl_cnt + (int64_t)blockIdx.x * T;
+        const int* lf = A0.rl_f + (int64_t)blockIdx.x * T * 8;
+        R* first = reinterpret_cast<R*>(lds) + (size_t)wv * kThreads;                       // [kWaves][256]
+        R* second = reinterpret_cast<R*>(lds) + (size_t)(kWaves + wv) * kThreads;           // [kWaves][256]
+        int* members = reinterpret_cast<int*>(lds + (size_t)2 * kWaves * kThreads * sizeof(R)) + (size_t)wv * kThreads;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) members[lane + 64 * c] = 0;
+        bool bad = false;                                   // (one wave: its LDS operations execute in order)
+        for (int t0 = s; t0 < e; t0 += 64) {
+            const int g = t0 + lane;
+            const int n = g < e ? list_count(cnt + g) : 0;
+            if (n > 8) bad = true;
+            if (n > 0 && n <= 8) {
+                const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)g * 8);
+                const int4 a = row[0], b = row[1];
+                const int fs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                R vs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vs[u] = fs[u] >= 0 ? G.r[(int64_t)g * F + fs[u]] : (R)0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (fs[u] < 0) continue;
+                    const int c = ((g - s) * F + fs[u]) & (kThreads - 1);
+                    const int at = atomicAdd(&members[c], 1);
+                    const R sq = vs[u] * vs[u];
+                    if (at == 0) first[c] = sq; else if (at == 1) second[c] = sq;
+                }
+            }
+        }
+        R p[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int m = members[lane + 64 * c];
+            if (m > 2) bad = true;
+            const R x0 = m > 0 ? first[lane + 64 * c] : (R)0, x1 = m > 1 ? second[lane + 64 * c] : (R)0;
+            const R h = (R)0 + x0;
+            p[c] = h + x1;
+        }
+        if (__ballot(bad) != 0ull) return false;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const R o = __shfl_down(p[c], m); p[c] = p[c] + o; }
+        }
+        const R a01 = p[0] + p[1], a23 = p[2] + p[3];
+        out = a01 + a23;
         return true;
     }
     template <typename SH>

@@ -51,10 +51,12 @@ names = ['select (per round)', 'bookkeeping', 'residual update', 're-correlation
 print('workgroup 0: %d atoms' % n)
 for i, nm in enumerate(names):
     print('  %-28s %9.0f cycles/atom' % (nm, v[32 + i] / n))
-print('  total %.0f cycles/atom' % (v[32:40].sum() / n))
+print('  total %.0f cycles/atom' % ((v[32:40].sum() + v[48:50].sum()) / n))
+print('    select / block arg-max %9.0f, compactions + sort %9.0f, weak-atom filter + rest = the select line above' % (v[48] / n, v[49] / n))
 sub = ['gather', 'pairing', 'sort', 'chains', 'row arg-max', 'list append (before the gather)']
 for i, nm in enumerate(sub):
     print('    re-correlation / %-14s %9.0f cycles/atom' % (nm, v[40 + i] / n))
+print('    re-correlation / row arg-max: %.0f cycles/atom of it in thread 0\'s own rows, the rest at the barrier' % (v[51] / n))
 cnt = (ctypes.c_ulonglong * 16)()
 lib.hscmp_debug_counters(cnt, 1)
 c = np.array(list(cnt), dtype=np.float64)
