@@ -197,9 +197,9 @@ template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R
         b = b + ob;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
+    lds_barrier();                                      // (scratch lives in LDS: no need to drain global stores here)
     if (lane == 0) { scratch[wv] = a; scratch[kWaves + wv] = b; }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         R a01 = scratch[0] + scratch[1];
         R a23 = scratch[2] + scratch[3];

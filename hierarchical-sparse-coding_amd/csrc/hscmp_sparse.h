@@ -90,10 +90,16 @@ template <typename R> __host__ __device__ inline size_t staged_list_bytes(const 
     const size_t b = (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8 + (size_t)A.nnz * sizeof(R);
     return b <= (size_t)kDictLdsBytes ? (b + 15) / 16 * 16 : 0;
 }
-// LDS bytes of the staged weights + by-feature lists (what does not fit stays in global memory)
+// (the per-atom list offsets: the residual update starts from them, K+1 ints)
+template <typename R> __host__ __device__ inline size_t staged_ptr_bytes(const DevParams& P, const SparseArgs<R>& A)
+{
+    const size_t b = ((size_t)P.K + 1) * sizeof(int);
+    return (A.nzptr && b <= (size_t)kWeightLdsBytes) ? (b + 15) / 16 * 16 : 0;
+}
+// LDS bytes of the staged weights + by-feature lists + per-atom offsets (what does not fit stays in global memory)
 template <typename R> __host__ __device__ inline size_t staged_dict_bytes(const DevParams& P, const SparseArgs<R>& A)
 {
-    return staged_weight_bytes(P, A) + staged_list_bytes(P, A);
+    return staged_weight_bytes(P, A) + staged_list_bytes(P, A) + staged_ptr_bytes(P, A);
 }
 
 // Arguments whose lists / weights point at their LDS copies at `base` (unchanged for what is not staged).
@@ -108,6 +114,7 @@ __device__ __forceinline__ SparseArgs<R> dict_view(const DevParams& P, const Spa
         B.fptr = fptr; B.fkw = fptr + (P.F + 1);
         B.fval = reinterpret_cast<const R*>(base + wb + (((size_t)(P.F + 1) + (size_t)A.nnz) * sizeof(int) + 7) / 8 * 8);
     }
+    if (staged_ptr_bytes(P, A)) B.nzptr = reinterpret_cast<const int*>(base + wb + staged_list_bytes(P, A));
     return B;
 }
 
@@ -121,6 +128,7 @@ __device__ __forceinline__ void stage_dict(const DevParams& P, const SparseArgs<
         for (int i = threadIdx.x; i <= P.F; i += kThreads) const_cast<int*>(B.fptr)[i] = A.fptr[i];
         for (int i = threadIdx.x; i < A.nnz; i += kThreads) { const_cast<int*>(B.fkw)[i] = A.fkw[i]; const_cast<R*>(B.fval)[i] = A.fval[i]; }
     }
+    if (staged_ptr_bytes(P, A)) for (int i = threadIdx.x; i <= P.K; i += kThreads) const_cast<int*>(B.nzptr)[i] = A.nzptr[i];
 }
 
 // LDS lists of one row block: a view into the policy's dynamic LDS (sizes = SparseCaps).
@@ -213,7 +221,7 @@ __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G
 {
     const int T = P.T, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, rowcap = L.caps.rows;
-    if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; }
+    if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
     __syncthreads();
     if (A.rl_cnt) {
         // listed cells: items = (window row, list slot); first the feature indices, then the values
@@ -221,7 +229,36 @@ __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
         constexpr int kV = 4;
-        const int items = nwin << shift;
+        const int items = C == 8 ? 0 : nwin << shift;
+        if (C == 8) {
+            // one thread per window row: its count and its list in one round trip, its cells in a second
+            for (int j = tid; j < nwin; j += kThreads) {
+                int gg = g0 + j;
+                bool ok = true;
+                if (reflect) gg = reflect_index(gg, sidx, nslice);
+                else ok = gg >= 0 && gg < T;
+                if (!ok) continue;
+                const int n = list_count(cnt + gg);
+                const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)gg * 8);
+                const int4 a = row[0], b = row[1];
+                if (n > C) {                              // overflowed list: the row goes to the dense scan below
+                    const int o = atomicAdd(&L.ctl[1], 1);
+                    if (o < rowcap) { L.rowj[o] = j; L.rowg[o] = gg; }
+                    continue;
+                }
+                if (n <= 0) continue;
+                const int fs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                R vs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vs[u] = fs[u] >= 0 ? G.r[(int64_t)gg * F + fs[u]] : (R)0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (vs[u] != (R)0) {
+                        const int o = atomicAdd(&L.ctl[0], 1);
+                        if (o < nzcap) { L.val[o] = vs[u]; L.key[o] = (fs[u] << 16) | j; }
+                    }
+            }
+        }
         for (int it0 = tid; it0 < items; it0 += kThreads * kV) {
             int g[kV], f[kV], j[kV], n[kV];
 #pragma unroll
@@ -323,21 +360,31 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
     if (A.fptr && n <= nzcap) {
         // ---- sparse window x sparse dictionary: only the non-zero products are formed.
         //  a. pair every input non-zero (f, j) with the dictionary non-zeros (k, w) of feature f: output row j - w
+        //     (all (input non-zero, list entry) combinations side by side: items = non-zeros x the longest list among them)
+        int* lbeg = L.perm; int* llen = reinterpret_cast<int*>(L.okey);        // [n] (both are free until the sort)
         for (int i = tid; i < n; i += kThreads) {
+            const int f = L.key[i] >> 16;
+            const int b = A.fptr[f], len = A.fptr[f + 1] - b;
+            lbeg[i] = b; llen[i] = len;
+            atomicMax(&L.ctl[3], len);
+        }
+        __syncthreads();
+        const int longest = L.ctl[3];
+        for (int it = tid; it < n * longest; it += kThreads) {
+            const int i = it / longest, sl = it - i * longest;
+            if (sl >= llen[i]) continue;
+            const int e = lbeg[i] + sl;
             const int key = L.key[i], f = key >> 16, j = key & 0xffff;
-            const R v = L.val[i];
-            const int e1 = A.fptr[f + 1];
-            for (int e = A.fptr[f]; e < e1; ++e) {
-                const int kw = A.fkw[e], w = kw & 0xffff, row = j - w;
-                if (row < 0 || row >= nrows) continue;
-                const int t = row0 + row;
-                if (t < 0 || t >= T) continue;
-                const int o = atomicAdd(&L.ctl[2], 1);
-                if (o < reccap) {
-                    L.rkey[o] = ((unsigned long long)row << 48) | ((unsigned long long)((unsigned)kw >> 16) << 32) |
-                                ((unsigned long long)f << 16) | (unsigned)w;
-                    L.rx[o] = v; L.rd[o] = A.fval[e];
-                }
+            const int kw = A.fkw[e], w = kw & 0xffff, row = j - w;
+            const R d = A.fval[e];
+            if (row < 0 || row >= nrows) continue;
+            const int t = row0 + row;
+            if (t < 0 || t >= T) continue;
+            const int o = atomicAdd(&L.ctl[2], 1);
+            if (o < reccap) {
+                L.rkey[o] = ((unsigned long long)row << 48) | ((unsigned long long)((unsigned)kw >> 16) << 32) |
+                            ((unsigned long long)f << 16) | (unsigned)w;
+                L.rx[o] = L.val[i]; L.rd[o] = d;
             }
         }
         __syncthreads();
@@ -592,37 +639,8 @@ template <typename R> struct SparseRecorr {
     // Issued before the residual update so that its memory round trips overlap with it; the window gather of
     // run() comes several barriers later.  (Distinct (w, f) of one atom are distinct cells, so no two threads
     // append the same member.)
-    static __device__ __forceinline__ void on_atom(const DevParams& P, const State<R>&, const Args& A0, char* lds, int p, int k)
-    {
-        if (!A0.rl_cnt) return;
-        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
-        const int T = P.T;
-        {
-            const int C = A.rl_cap;
-            int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
-            int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
-            const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1];
-            for (int e = e0 + (int)threadIdx.x; e < e1; e += kThreads) {
-                const int wf = A.nzwf[e], f = wf & 0xffff, g = p - P.off + (wf >> 16);
-                if (g < 0 || g >= T) continue;                         // clipped part of the atom (utils.py:110-129)
-                // the whole list of the row in one go (empty slots hold -1 and never match); an overflowed row
-                // (count > C) is read densely anyway
-                const int n = list_count(cnt + g);
-                bool listed = n > C;
-                if (C == 8) {
-                    const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)g * 8);
-                    const int4 a = row[0], b = row[1];
-                    listed |= a.x == f || a.y == f || a.z == f || a.w == f || b.x == f || b.y == f || b.z == f || b.w == f;
-                } else {
-                    for (int q = 0; q < C; ++q) listed |= lf[(int64_t)g * C + q] == f;
-                }
-                if (!listed) {
-                    const int o = atomicAdd(&cnt[g], 1);
-                    if (o < C) lf[(int64_t)g * C + o] = f;
-                }
-            }
-        }
-    }
+    // (the cells an atom touches are entered in the row lists by update_residual, next to its gather)
+    static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
     // Residual subtraction with the local energies (modeling.py:996-1016) over the listed cells only.  The dense form
     // streams the whole W x F window and the dense atom (96 KB per atom at BASELINE config 4: the loop's HBM traffic);
     // here the span's listed non-zero cells are gathered, the atom's few non-zeros are applied to them (new cells
@@ -641,23 +659,88 @@ template <typename R> struct SparseRecorr {
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
         int* key = L.key; R* before = L.val; R* after = L.rd; int* order = L.perm;
         const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1];
-        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; }
-        __syncthreads();
-        // the span's listed cells (the atom's own cells were listed by on_atom: a new one still holds 0 and is skipped here)
-        const int items = (e - s) << shift;
-        for (int it = tid; it < items; it += kThreads) {
-            const int g = s + (it >> shift);
-            const int n = list_count(cnt + g);
-            if (n > C) { if ((it & (C - 1)) == 0) atomicAdd(&L.ctl[1], 1); continue; }
-            const int f = lf[((int64_t)g << shift) + (it & (C - 1))];
-            if (f < 0) continue;
-            const R v = G.r[(int64_t)g * F + f];
-            if (v != (R)0) {
-                const int o = atomicAdd(&L.ctl[0], 1);
-                if (o < L.caps.nz) { key[o] = (g - s) * F + f; before[o] = v; after[o] = v; }
+        int* members = L.perm; int* slot0 = reinterpret_cast<int*>(L.okey); int* slot1 = reinterpret_cast<int*>(L.rkey);   // [256] each
+        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[3] = 0; }
+        members[tid] = 0;
+        lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
+        // Two jobs share the memory round trips.  (a) Row threads (from thread 0 up) gather the span's listed cells:
+        // a row's count and list in one trip, its cells in the next.  (b) Atom threads (from the last thread down)
+        // enter the atom's cells in the row lists (the window gathers read them instead of scanning rows of F values):
+        // the atom's non-zero, then the row's list; an unlisted cell takes the next free slot.  A cell entered under (b)
+        // still holds 0 and is skipped by (a) whether (a) sees it or not; a count pushed past the capacity is seen by
+        // every later reader as "read the row densely".
+        const int na = e1 - e0;
+        int* cntw = A.rl_cnt + (int64_t)blockIdx.x * T;
+        int* lfw = A.rl_f + (int64_t)blockIdx.x * T * C;
+        if (C == 8) {
+            for (int base = 0; base < max(e - s, na); base += kThreads) {
+                const int g = s + base + tid;                                // (a) this thread's row
+                const bool row_on = g < e;
+                const int gq = row_on ? g : s;
+                const int qa = base + (kThreads - 1 - tid);                  // (b) this thread's non-zero of the atom
+                const bool atom_on = qa < na;
+                const int q = e0 + (atom_on ? qa : 0);
+                // first trip
+                const int n = list_count(cnt + gq);
+                const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)gq * 8);
+                const int4 a = row[0], b = row[1];
+                const int wf = na > 0 ? A.nzwf[q] : 0;
+                // second trip
+                const int fa = wf & 0xffff;
+                int ga = p - P.off + (wf >> 16);
+                const bool cell_on = atom_on && ga >= 0 && ga < T;            // clipped part of the atom (utils.py:110-129)
+                if (!cell_on) ga = s;
+                const int fs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                const bool cells_on = row_on && n > 0 && n <= C;
+                R vs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vs[u] = (cells_on && fs[u] >= 0) ? G.r[(int64_t)g * F + fs[u]] : (R)0;
+                const int n2 = list_count(cnt + ga);
+                const int4* row2 = reinterpret_cast<const int4*>(lf + (int64_t)ga * 8);
+                const int4 a2 = row2[0], b2 = row2[1];
+                if (row_on && n > C) atomicAdd(&L.ctl[1], 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!(vs[u] != (R)0)) continue;
+                    const int o = atomicAdd(&L.ctl[0], 1);
+                    if (o < L.caps.nz) { key[o] = (g - s) * F + fs[u]; before[o] = vs[u]; after[o] = vs[u]; }
+                }
+                if (cell_on) {
+                    // (empty slots hold -1 and never match; an overflowed row, count > C, is read densely anyway)
+                    const bool listed = n2 > C || a2.x == fa || a2.y == fa || a2.z == fa || a2.w == fa ||
+                                        b2.x == fa || b2.y == fa || b2.z == fa || b2.w == fa;
+                    if (!listed) {
+                        const int o = atomicAdd(&cntw[ga], 1);
+                        if (o < C) lfw[(int64_t)ga * C + o] = fa;
+                    }
+                }
+            }
+        } else {
+            for (int q = e0 + tid; q < e1; q += kThreads) {
+                const int wf = A.nzwf[q], f = wf & 0xffff, g = p - P.off + (wf >> 16);
+                if (g < 0 || g >= T) continue;
+                bool listed = list_count(cnt + g) > C;
+                for (int u = 0; u < C; ++u) listed |= lf[(int64_t)g * C + u] == f;
+                if (!listed) {
+                    const int o = atomicAdd(&cntw[g], 1);
+                    if (o < C) lfw[(int64_t)g * C + o] = f;
+                }
+            }
+            const int items = (e - s) << shift;
+            for (int it = tid; it < items; it += kThreads) {
+                const int g = s + (it >> shift);
+                const int n = list_count(cnt + g);
+                if (n > C) { if ((it & (C - 1)) == 0) atomicAdd(&L.ctl[1], 1); continue; }
+                const int f = lf[((int64_t)g << shift) + (it & (C - 1))];
+                if (f < 0) continue;
+                const R v = G.r[(int64_t)g * F + f];
+                if (v != (R)0) {
+                    const int o = atomicAdd(&L.ctl[0], 1);
+                    if (o < L.caps.nz) { key[o] = (g - s) * F + f; before[o] = v; after[o] = v; }
+                }
             }
         }
-        __syncthreads();
+        lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
         const int n0 = L.ctl[0];
         if (L.ctl[1] > 0 || n0 + (e1 - e0) > L.caps.nz) return false;                 // uniform
         // the atom's non-zeros: -c*D[k] rounded, then += (utils.py:120,129)
@@ -678,8 +761,33 @@ template <typename R> struct SparseRecorr {
             }
             G.r[(int64_t)g * F + f] = vn;
         }
-        __syncthreads();
+        lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
         const int n = L.ctl[0];
+        // Energy partial sums: partial q sums the cells with index = q mod 256 in ascending order.  With at most two
+        // cells per partial sum the order does not matter (0 + a = a, a + b = b + a): every cell registers with its
+        // partial sum and thread q adds what it finds.  A third cell somewhere: sort and walk, as the order prescribes.
+        for (int j = tid; j < n; j += kThreads) {
+            const int cq = key[j] & (kThreads - 1);
+            const int at = atomicAdd(&members[cq], 1);
+            if (at == 0) slot0[cq] = j; else if (at == 1) slot1[cq] = j; else L.ctl[3] = 1;
+        }
+        lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
+        if (L.ctl[3] == 0) {                                                          // uniform
+            const int m = members[tid];
+            if (m > 0) {
+                const int j = slot0[tid];
+                const R b = before[j], a = after[j];
+                const R sb = b * b, sa = a * a;
+                pb = pb + sb; pa = pa + sa;
+            }
+            if (m > 1) {
+                const int j = slot1[tid];
+                const R b = before[j], a = after[j];
+                const R sb = b * b, sa = a * a;
+                pb = pb + sb; pa = pa + sa;
+            }
+            return true;
+        }
         for (int j = tid; j < n; j += kThreads) {                                     // rank sort by cell index (distinct)
             const int kj = key[j];
             int rank = 0;
@@ -808,7 +916,7 @@ template <typename R> struct SparseRecorr {
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
         unsigned* bits = has_bits(P, A) ? bits_of(P, A0, lds) : nullptr;
         if (A.rl_cnt) {
-            // (the atom's cells were added to the row lists by on_atom(), before the residual update)
+            // (the atom's cells were entered in the row lists by update_residual)
         } else if (bits) {
             // the atom just subtracted made its span possibly non-zero (utils.py:76-131)
             int s, e, es;
