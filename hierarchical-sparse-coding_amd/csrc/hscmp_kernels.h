@@ -349,6 +349,7 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     R part_c[WITH_PART ? kThreads : 1];
     int part_k[WITH_PART ? kThreads : 1];
     R red[2 * kWaves];
+    unsigned touched[(MAXSEG + 31) / 32];     // step-by-step body, blocked rounds: segments whose maxima are refreshed at the round end
     // blocked selection (:908-962): raw / ordered candidate lists of a round (longer lists live in State::sel_*)
     int sel_t[2 * kSelLds]; int sel_k[2 * kSelLds]; R sel_c[2 * kSelLds];
     Cand<R> cred[kWaves];
@@ -457,6 +458,40 @@ __device__ __forceinline__ void scan_segment(const DevParams& P, const Sig<R>& G
         sh.seg_t[sg] = win.i;
         if constexpr (!SO) { sh.seg_c[sg] = G.bc[win.i]; sh.seg_k[sg] = G.bk[win.i]; }
     }
+}
+
+// scan_segment for a policy that still holds the rows it just re-correlated in LDS (rows [rt0, rt0+rn): atom rk,
+// INT_MAX = the default winner k = 0 with coefficient r0, else coefficient rc): those positions are taken from LDS,
+// the others from global memory, so the scan does not wait for the rows' global stores.  Same maxima.
+template <typename R, typename SH>
+__device__ __forceinline__ void scan_segment_rows(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane,
+                                                  const int* rk, const R* rc, const R* r0, int rt0, int rn)
+{
+    const int t0 = (sg << P.seg_shift);
+    const int t1 = min(P.T, t0 + P.seg);
+    auto fetch = [&](int t, R& c, int& k) {
+        const int row = t - rt0;
+        if (row >= 0 && row < rn) { k = rk[row]; if (k == INT_MAX) { k = 0; c = r0[row]; } else c = rc[row]; }
+        else { c = G.bc[t]; k = G.bk[t]; }
+    };
+    Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+    R bc = (R)0;
+    int bk = 0;
+    for (int t = t0 + lane; t < t1; t += 64) {
+        R c; int k;
+        fetch(t, c, k);
+        const R sc = score_of(c, k, w);
+        if (sc > best.s) { best.s = sc; best.i = t; bc = c; bk = k; }
+    }
+    Cand<R> win = wave_argmax(best);
+    if (win.i == INT_MAX) {
+        win.i = t0; win.s = (R)0;
+        fetch(t0, bc, bk);                                   // (every lane: uniform)
+    } else {
+        const int owner = __ffsll((long long)__ballot(best.i == win.i)) - 1;
+        bc = __shfl(bc, owner); bk = __shfl(bk, owner);
+    }
+    if (lane == 0) { sh.seg_score[sg] = win.s; sh.seg_t[sg] = win.i; sh.seg_c[sg] = bc; sh.seg_k[sg] = bk; }
 }
 
 // arg-max of the per-position best over the block [lo,hi) by one wave, through the segment maxima:
@@ -602,6 +637,7 @@ template <typename R> struct GenericRecorr {
                                                            int, int, int, R&, R&) { return false; }
     static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const Args&, char*, int, int, R&) { return false; }
     static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const Args&, char*, int, int, int, int, R&) { return false; }
+    static __device__ __forceinline__ bool row_results(const DevParams&, const Args&, char*, int, const int*&, const R*&, const R*&, int&, int&) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -729,6 +765,7 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
     }
     if constexpr (!Recorr::kFused) {
+        for (int i = tid; i < (Recorr::kMaxSegments + 31) / 32; i += kThreads) sh.touched[i] = 0u;
         // Bloom filter over the (t,k) pairs that already own a coefficient slot (rebuilt on every launch)
         for (int i = tid; i < kBloomWords; i += kThreads) sh.bloom[i] = 0u;
         __syncthreads();
@@ -1049,14 +1086,28 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
             if constexpr (!Recorr::kFused) HSCMP_STAMP(34);
             // ---- :1120, :1018-1051 local re-correlation of the 2W-1 touched rows
             Recorr::run(P, S, G, sh, A, plds, p, k);
-            __syncthreads();
+            // (a policy that still holds the rows' results in LDS lets the segment scan start before their stores land)
+            const int* rows_k = nullptr; const R* rows_c = nullptr; const R* rows_0 = nullptr;
+            int rows_t0 = 0, rows_n = 0;
+            bool rows_lds = false;
+            if constexpr (!Recorr::kFused && !Recorr::kScoreOnly) rows_lds = Recorr::row_results(P, A, plds, p, rows_k, rows_c, rows_0, rows_t0, rows_n);
+            if (!rows_lds) __syncthreads();
             if constexpr (!Recorr::kFused) HSCMP_STAMP(35);
 
             // ---- refresh the maxima of the touched segments
             {
                 const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
                 const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
-                for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
+                if (P.blocked) {
+                    // the maxima are only read by the next selection: the atoms of a blocked round mark their segments,
+                    // which are rescanned once at the round end (no global round trip per atom)
+                    if (tid == 0) for (int sg = sg0; sg <= sg1; ++sg) sh.touched[sg >> 5] |= 1u << (sg & 31);
+                } else if (rows_lds) {
+                    if constexpr (!Recorr::kScoreOnly)
+                        for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment_rows(P, G, wts, sh, sg, lane, rows_k, rows_c, rows_0, rows_t0, rows_n);
+                } else {
+                    for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
+                }
             }
 
             // ---- :1122-1142 fast stop rules
@@ -1075,6 +1126,26 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
         }
 
         if constexpr (!Recorr::kFused) {
+            // blocked rounds: maxima of the segments the round's atoms touched (their stores are behind the atoms' barriers)
+            if (P.blocked && nsel > 0 && !sh.converged) {
+                // every wave walks the set bits (lane l holds word l) and takes the segments sg = wave (mod 4)
+                constexpr int kWords = (Recorr::kMaxSegments + 31) / 32;
+                static_assert(kWords <= 64, "one mask word per lane");
+                const unsigned word = lane < kWords ? sh.touched[lane] : 0u;
+                unsigned long long words = __ballot(word != 0u);
+                while (words) {                                             // wave-uniform
+                    const int wl = __ffsll((long long)words) - 1;
+                    words &= words - 1ull;
+                    unsigned bits = __shfl(word, wl);
+                    while (bits) {
+                        const int sg = wl * 32 + __ffs((int)bits) - 1;
+                        bits &= bits - 1u;
+                        if ((sg & (kWaves - 1)) != wv) continue;
+                        scan_segment<Recorr::kScoreOnly>(P, G, wts, sh, sg, lane);
+                        if (lane == 0) atomicAnd(&sh.touched[sg >> 5], ~(1u << (sg & 31)));
+                    }
+                }
+            }
             // blocked rounds: the new slots of the round enter the table (thread 0's notes are behind the atoms' barriers)
             if (hashed && P.blocked)
                 for (int i = tid; i < nsel; i += kThreads) {

@@ -343,7 +343,7 @@ __device__ __forceinline__ unsigned long long score_bits(float s) { return (unsi
 template <typename R>
 __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& S, const Sig<R>& G, const SparseArgs<R>& A,
                                             const SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
-                                            int sidx, int nslice)
+                                            int sidx, int nslice, bool gathered = false)
 {
     const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, reccap = L.caps.rec;
@@ -353,7 +353,16 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
 
     // ---- 1. the non-zeros of the window (any order)
     HSCMP_STAMP_BEGIN();
-    const int n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
+    int n;
+    if (gathered) {
+        // (SparseRecorr::merged_update left the window's cells in L.key / L.val; a cell the atom cancelled holds 0)
+        n = L.ctl[0];
+        __syncthreads();
+        if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
+        __syncthreads();
+    } else {
+        n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
+    }
     HSCMP_STAMP(40);
     HSCMP_TALLY(0, 1); HSCMP_TALLY(1, n); HSCMP_TALLY(2, n > nzcap); HSCMP_TALLY(5, L.ctl[1]);
 
@@ -364,7 +373,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
         int* lbeg = L.perm; int* llen = reinterpret_cast<int*>(L.okey);        // [n] (both are free until the sort)
         for (int i = tid; i < n; i += kThreads) {
             const int f = L.key[i] >> 16;
-            const int b = A.fptr[f], len = A.fptr[f + 1] - b;
+            const int b = A.fptr[f], len = (L.val[i] != (R)0) ? A.fptr[f + 1] - b : 0;     // (a zero factor adds nothing)
             lbeg[i] = b; llen[i] = len;
             atomicMax(&L.ctl[3], len);
         }
@@ -502,6 +511,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     if (k == INT_MAX) { G.bc[t] = c0[row]; G.bk[t] = 0; }
                     else { G.bc[t] = rc[row]; G.bk[t] = k; }
                 }
+                if (tid == 0) L.ctl[3] = -3;                             // rk / rc / c0 hold the rows' results (SparseRecorr::row_results)
             } else {
                 // (more rows than list entries: one thread per row walks its bucket, ascending k inside a row)
                 for (int row = tid; row < nrows; row += kThreads) {
@@ -523,7 +533,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 }
             }
             HSCMP_STAMP(51);
-            __syncthreads();
+            lds_barrier();       // (LDS lists: free for the next use.  The rows' global stores drain at the caller's next full barrier)
             HSCMP_STAMP(44);
             return;
         }
@@ -641,6 +651,126 @@ template <typename R> struct SparseRecorr {
     // append the same member.)
     // (the cells an atom touches are entered in the row lists by update_residual, next to its gather)
     static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
+    // Residual update and window gather in one: away from the signal's ends the 3W-2 rows the re-correlation will gather
+    // (run(), below) contain the atom's span, so they are gathered ONCE, before the subtraction; the atom's non-zeros
+    // are applied to the LDS copy as well as to the residual, the energy partial sums are taken over the span's part,
+    // and the list (L.key / L.val in gather_window's encoding, count in ctl[0]) is left for sparse_rows (ctl[3] = -2; other values of
+    // that word are list lengths and flags >= 0).
+    // Returns false, with nothing changed but the row lists, when a row list of the window has overflowed, the cells
+    // do not fit, or three cells meet in one partial sum: update_residual then runs its span-only form.
+    static __device__ __forceinline__ bool merged_update(const DevParams& P, const Sig<R>& G, const Args& A, const SparseLds<R>& L,
+                                                         int p, int k, R c, int s, int e, R& pb, R& pa)
+    {
+        const int T = P.T, F = P.F, W = P.W, tid = threadIdx.x;
+        const int g0 = p - P.off - (W - 1), nwin = 3 * W - 2;
+        const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
+        const int* lf = A.rl_f + (int64_t)blockIdx.x * T * 8;
+        int* cntw = A.rl_cnt + (int64_t)blockIdx.x * T;
+        int* lfw = A.rl_f + (int64_t)blockIdx.x * T * 8;
+        int* key = L.key; R* cur = L.val; R* before = L.rx;
+        int* members = L.perm; int* slot0 = reinterpret_cast<int*>(L.okey); int* slot1 = reinterpret_cast<int*>(L.rkey);   // [256] each
+        const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1], na = e1 - e0;
+        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
+        members[tid] = 0;
+        lds_barrier();
+        // (a) row threads, from thread 0 up: count + list of a window row, then its cells; (b) atom threads, from the last
+        // thread down: the atom's non-zero, then the list of its row, and an unlisted cell takes the next free slot
+        for (int base = 0; base < max(nwin, na); base += kThreads) {
+            const int j = base + tid;
+            const bool row_on = j < nwin;
+            const int g = g0 + (row_on ? j : 0);
+            const int qa = base + (kThreads - 1 - tid);
+            const bool atom_on = qa < na;
+            const int q = e0 + (atom_on ? qa : 0);
+            const int n = list_count(cnt + g);
+            const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)g * 8);
+            const int4 a = row[0], b = row[1];
+            const int wf = na > 0 ? A.nzwf[q] : 0;
+            const int fa = wf & 0xffff;
+            const int ga = atom_on ? p - P.off + (wf >> 16) : g0;         // inside the window, which is inside the signal
+            const int fs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const bool cells_on = row_on && n > 0 && n <= 8;
+            R vs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vs[u] = (cells_on && fs[u] >= 0) ? G.r[(int64_t)g * F + fs[u]] : (R)0;
+            const int n2 = list_count(cnt + ga);
+            const int4* row2 = reinterpret_cast<const int4*>(lf + (int64_t)ga * 8);
+            const int4 a2 = row2[0], b2 = row2[1];
+            if (row_on && n > 8) atomicAdd(&L.ctl[1], 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (!(vs[u] != (R)0)) continue;
+                const int o = atomicAdd(&L.ctl[0], 1);
+                if (o < L.caps.nz) { key[o] = (fs[u] << 16) | j; before[o] = vs[u]; cur[o] = vs[u]; }
+            }
+            if (atom_on) {
+                const bool listed = n2 > 8 || a2.x == fa || a2.y == fa || a2.z == fa || a2.w == fa ||
+                                    b2.x == fa || b2.y == fa || b2.z == fa || b2.w == fa;
+                if (!listed) {
+                    const int o = atomicAdd(&cntw[ga], 1);
+                    if (o < 8) lfw[(int64_t)ga * 8 + o] = fa;
+                }
+            }
+        }
+        lds_barrier();
+        const int n0 = L.ctl[0];
+        if (L.ctl[1] > 0 || n0 + na > L.caps.nz || na > kThreads) return false;      // uniform
+        // Partial sums first (nothing is written to the residual before the form is settled): the span's cells register
+        // with partial sum (cell index mod 256); an atom cell that is not in the list yet joins with value 0.
+        const int js = s - g0, je = e - g0;                                           // the span's rows inside the window
+        const R nc = -c;
+        int slot = -1;                                                              // atom thread: list entry of its cell
+        R prod = (R)0;
+        int wfq = 0;
+        {
+            const int qa = kThreads - 1 - tid;
+            if (qa < na) {                                                           // (na <= 256: one per thread)
+                wfq = A.nzwf[e0 + qa];
+                prod = nc * A.nzval[e0 + qa];                                        // -c*D[k] rounded, then += (utils.py:120,129)
+                const int kk = ((wfq & 0xffff) << 16) | (p - P.off + (wfq >> 16) - g0);
+                int jj = n0;
+                for (int j0 = 0; j0 < n0 && jj == n0; j0 += 4) {                    // four list entries per LDS round trip
+                    const int k0 = key[j0], k1 = j0 + 1 < n0 ? key[j0 + 1] : -1, k2 = j0 + 2 < n0 ? key[j0 + 2] : -1, k3 = j0 + 3 < n0 ? key[j0 + 3] : -1;
+                    jj = k0 == kk ? j0 : k1 == kk ? j0 + 1 : k2 == kk ? j0 + 2 : k3 == kk ? j0 + 3 : n0;
+                }
+                if (jj < n0) slot = jj;
+                else { slot = n0 + atomicAdd(&L.ctl[2], 1); key[slot] = kk; before[slot] = (R)0; cur[slot] = (R)0; }   // (ctl[0] is still being read)
+            }
+        }
+        lds_barrier();
+        const int n = n0 + L.ctl[2];
+        for (int i = tid; i < n; i += kThreads) {
+            const int kk = key[i], j = kk & 0xffff;
+            if (j < js || j >= je) continue;
+            const int cq = ((j - js) * F + (kk >> 16)) & (kThreads - 1);
+            const int at = atomicAdd(&members[cq], 1);
+            if (at == 0) slot0[cq] = i; else if (at == 1) slot1[cq] = i; else L.ctl[3] = 1;
+        }
+        lds_barrier();
+        if (L.ctl[3] != 0) return false;                                              // uniform; the list appends stay (harmless)
+        // the atom's non-zeros: residual and LDS copy
+        if (slot >= 0) {
+            const R vn = before[slot] + prod;
+            cur[slot] = vn;
+            G.r[(int64_t)(p - P.off + (wfq >> 16)) * F + (wfq & 0xffff)] = vn;
+        }
+        lds_barrier();
+        const int m = members[tid];
+        if (m > 0) {
+            const int i = slot0[tid];
+            const R b = before[i], a = cur[i];
+            const R sb = b * b, sa = a * a;
+            pb = pb + sb; pa = pa + sa;
+        }
+        if (m > 1) {
+            const int i = slot1[tid];
+            const R b = before[i], a = cur[i];
+            const R sb = b * b, sa = a * a;
+            pb = pb + sb; pa = pa + sa;
+        }
+        if (tid == 0) { L.ctl[0] = n; L.ctl[3] = -2; }                                 // the window list is ready for run()
+        return true;
+    }
     // Residual subtraction with the local energies (modeling.py:996-1016) over the listed cells only.  The dense form
     // streams the whole W x F window and the dense atom (96 KB per atom at BASELINE config 4: the loop's HBM traffic);
     // here the span's listed non-zero cells are gathered, the atom's few non-zeros are applied to them (new cells
@@ -657,10 +787,17 @@ template <typename R> struct SparseRecorr {
         const int T = P.T, F = P.F, tid = threadIdx.x, C = A.rl_cap, shift = __ffs(C) - 1;
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
+        {
+            const int g0 = p - P.off - (P.W - 1);
+            if (C == 8 && g0 >= 0 && g0 + 3 * P.W - 2 <= T && 3 * P.W - 2 <= 0xffff) {
+                if (merged_update(P, G, A, L, p, k, c, s, e, pb, pa)) return true;
+                lds_barrier();               // every thread has read the counters that settled it before they are reset below
+            }
+        }
         int* key = L.key; R* before = L.val; R* after = L.rd; int* order = L.perm;
         const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1];
         int* members = L.perm; int* slot0 = reinterpret_cast<int*>(L.okey); int* slot1 = reinterpret_cast<int*>(L.rkey);   // [256] each
-        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[3] = 0; }
+        if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
         members[tid] = 0;
         lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
         // Two jobs share the memory round trips.  (a) Row threads (from thread 0 up) gather the span's listed cells:
@@ -756,13 +893,13 @@ template <typename R> struct SparseRecorr {
             if (j < n0) { vn = before[j] + prod; after[j] = vn; }
             else {
                 vn = (R)0 + prod;
-                const int o = atomicAdd(&L.ctl[0], 1);
+                const int o = n0 + atomicAdd(&L.ctl[2], 1);                           // (ctl[0] is still being read)
                 key[o] = i; before[o] = (R)0; after[o] = vn;
             }
             G.r[(int64_t)g * F + f] = vn;
         }
         lds_barrier();                                                                // (LDS lists only; the global stores drain at the caller's barrier)
-        const int n = L.ctl[0];
+        const int n = n0 + L.ctl[2];
         // Energy partial sums: partial q sums the cells with index = q mod 256 in ascending order.  With at most two
         // cells per partial sum the order does not matter (0 + a = a, a + b = b + a): every cell registers with its
         // partial sum and thread q adds what it finds.  A third cell somewhere: sort and walk, as the order prescribes.
@@ -906,6 +1043,15 @@ template <typename R> struct SparseRecorr {
         out = a01 + a23;
         return true;
     }
+    // After run(): the rows p-(W-1) .. p+(W-1) as the arg-max over listed outputs left them in LDS (see sparse_rows, step d)
+    static __device__ __forceinline__ bool row_results(const DevParams& P, const Args& A0, char* lds, int p, const int*& rk, const R*& rc,
+                                                       const R*& r0, int& t0, int& n)
+    {
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        if (L.ctl[3] != -3) return false;                  // uniform: written before the last barrier of sparse_rows
+        rk = L.perm; rc = L.rd; r0 = L.rx; t0 = p - (P.W - 1); n = 2 * P.W - 1;
+        return true;
+    }
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G, SH&, const Args& A0,
                                                char* lds, int p, int k)
@@ -928,7 +1074,8 @@ template <typename R> struct SparseRecorr {
         const int sidx = tstart < 0 ? 0 : tstart;          // :1034
         const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
         HSCMP_STAMP(45);
-        sparse_rows(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1);
+        const bool gathered = A.rl_cnt && L.ctl[3] == -2;     // uniform: written before the barriers of the energy tree
+        sparse_rows(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1, gathered);
     }
 };
 
