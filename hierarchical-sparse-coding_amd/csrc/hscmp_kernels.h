@@ -638,6 +638,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const Args&, char*, int, int, R&) { return false; }
     static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const Args&, char*, int, int, int, int, R&) { return false; }
     static __device__ __forceinline__ bool row_results(const DevParams&, const Args&, char*, int, const int*&, const R*&, const R*&, int&, int&) { return false; }
+    static __device__ __forceinline__ bool residual_copy_in_lds(const Args&, char*) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
     static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
@@ -1077,7 +1078,9 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 const R loss = pb - pa;              // :1005
                 sh.e_res = sh.e_res - loss;          // :1014
             }
-            __syncthreads();                         // residual writes visible to the whole workgroup
+            // residual writes visible to the whole workgroup -- unless the policy re-correlates from its own LDS copy of
+            // the window and nothing else reads the residual before the atom's last barrier
+            if (!P.has_scale && Recorr::residual_copy_in_lds(A, plds)) lds_barrier(); else __syncthreads();
             if (P.has_scale) {
                 const int sg0 = s >> P.seg_shift, sg1 = (e - 1) >> P.seg_shift;
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);

@@ -556,6 +556,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, R&) { return false; }
     static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const MfmaArgsT<R>&, char*, int, int, int, int, R&) { return false; }
     static __device__ __forceinline__ bool row_results(const DevParams&, const MfmaArgsT<R>&, char*, int, const int*&, const R*&, const R*&, int&, int&) { return false; }
+    static __device__ __forceinline__ bool residual_copy_in_lds(const MfmaArgsT<R>&, char*) { return false; }
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
 

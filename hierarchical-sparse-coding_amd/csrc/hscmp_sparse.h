@@ -357,9 +357,9 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
     if (gathered) {
         // (SparseRecorr::merged_update left the window's cells in L.key / L.val; a cell the atom cancelled holds 0)
         n = L.ctl[0];
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
-        __syncthreads();
+        lds_barrier();
     } else {
         n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
     }
@@ -368,6 +368,8 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
 
     if (A.fptr && n <= nzcap) {
         // ---- sparse window x sparse dictionary: only the non-zero products are formed.
+        //  (every barrier of this branch orders LDS lists only -- lds_barrier: the residual / row-list stores of the
+        //   update that went before keep draining underneath)
         //  a. pair every input non-zero (f, j) with the dictionary non-zeros (k, w) of feature f: output row j - w
         //     (all (input non-zero, list entry) combinations side by side: items = non-zeros x the longest list among them)
         int* lbeg = L.perm; int* llen = reinterpret_cast<int*>(L.okey);        // [n] (both are free until the sort)
@@ -377,7 +379,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             lbeg[i] = b; llen[i] = len;
             atomicMax(&L.ctl[3], len);
         }
-        __syncthreads();
+        lds_barrier();
         const int longest = L.ctl[3];
         for (int it = tid; it < n * longest; it += kThreads) {
             const int i = it / longest, sl = it - i * longest;
@@ -396,7 +398,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 L.rx[o] = L.val[i]; L.rd[o] = d;
             }
         }
-        __syncthreads();
+        lds_barrier();
         const int m = L.ctl[2];
         HSCMP_STAMP(41);
         HSCMP_TALLY(3, m); HSCMP_TALLY(4, m > reccap);
@@ -408,9 +410,9 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             int* start = L.rowg;                     // [nrows+1]
             if (bucketed) {
                 for (int r = tid; r < nrows; r += kThreads) cnt[r] = 0;
-                __syncthreads();
+                lds_barrier();
                 for (int i = tid; i < m; i += kThreads) atomicAdd(&cnt[(int)(L.rkey[i] >> 48)], 1);
-                __syncthreads();
+                lds_barrier();
                 if (wv == 0) {
                     // exclusive prefix sum over the rows by one wave: each lane owns a run of rows
                     const int per = (nrows + 63) >> 6;
@@ -422,15 +424,15 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     for (int q = 0; q < per; ++q) { const int r = lane * per + q; if (r < nrows) { start[r] = run; run += cnt[r]; } }
                     if (lane == 63) start[nrows] = incl;
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int r = tid; r < nrows; r += kThreads) cnt[r] = 0;          // cursors
-                __syncthreads();
+                lds_barrier();
                 unsigned* member = L.okey;           // bucket members (record indices); okey proper is written in step c
                 for (int i = tid; i < m; i += kThreads) {
                     const int r = (int)(L.rkey[i] >> 48);
                     member[start[r] + atomicAdd(&cnt[r], 1)] = (unsigned)i;
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int i = tid; i < m; i += kThreads) {
                     const unsigned long long key = L.rkey[i];
                     const int r = (int)(key >> 48), b0 = start[r], b1 = start[r + 1];
@@ -442,11 +444,19 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 for (int i = tid; i < m; i += kThreads) {
                     const unsigned long long key = L.rkey[i];
                     int rank = 0;
-                    for (int q = 0; q < m; ++q) rank += (L.rkey[q] < key) ? 1 : 0;
+                    int q = 0;
+                    for (; q + 8 <= m; q += 8) {                         // eight keys per LDS round trip
+                        unsigned long long kq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) kq[u] = L.rkey[q + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) rank += (kq[u] < key) ? 1 : 0;
+                    }
+                    for (; q < m; ++q) rank += (L.rkey[q] < key) ? 1 : 0;
                     L.perm[rank] = i;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             HSCMP_STAMP(42);
             //  c. one chain per output, run by the thread of its first record (f outer, w inner from +0)
             for (int sp = tid; sp < m; sp += kThreads) {
@@ -464,7 +474,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 }
                 L.okey[sp] = mark;
             }
-            __syncthreads();
+            lds_barrier();
             HSCMP_STAMP(43);
             //  d. per-row best over atoms: the listed outputs against the zeros of all the others -- a zero score never
             //     beats k = 0, the first of the ties; among equal scores the lowest atom wins (np.argmax).
@@ -476,7 +486,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                 int* rk = L.perm;
                 R* c0 = L.rx; R* rc = L.rd;
                 for (int row = tid; row < nrows; row += kThreads) { rmax[row] = 0ull; rk[row] = INT_MAX; c0[row] = (R)0; }
-                __syncthreads();
+                lds_barrier();
                 for (int sp = tid; sp < m; sp += kThreads) {
                     const unsigned ok = L.okey[sp];
                     if (ok == ~0u) continue;
@@ -486,7 +496,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     const R sc = score_of(o, kk, A.wts);
                     if (sc > (R)0) atomicMax(&rmax[row], score_bits(sc));
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int sp = tid; sp < m; sp += kThreads) {
                     const unsigned ok = L.okey[sp];
                     if (ok == ~0u) continue;
@@ -494,7 +504,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     const R sc = score_of(L.out[sp], kk, A.wts);
                     if (sc > (R)0 && score_bits(sc) == rmax[row]) atomicMin(&rk[row], kk);
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int sp = tid; sp < m; sp += kThreads) {
                     const unsigned ok = L.okey[sp];
                     if (ok == ~0u) continue;
@@ -503,7 +513,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                     const R sc = score_of(o, kk, A.wts);
                     if (sc > (R)0 && score_bits(sc) == rmax[row] && kk == rk[row]) rc[row] = o;
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int row = tid; row < nrows; row += kThreads) {
                     const int t = row0 + row;
                     if (t < 0 || t >= T) continue;                       // overlapReplace clipping (utils.py:133-161)
@@ -672,9 +682,15 @@ template <typename R> struct SparseRecorr {
         const int e0 = A.nzptr[k], e1 = A.nzptr[k + 1], na = e1 - e0;
         if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
         members[tid] = 0;
+        HSCMP_STAMP_BEGIN();
         lds_barrier();
+        HSCMP_STAMP(52);
         // (a) row threads, from thread 0 up: count + list of a window row, then its cells; (b) atom threads, from the last
         // thread down: the atom's non-zero, then the list of its row, and an unlisted cell takes the next free slot
+        // (the first 256 non-zeros of the atom stay with their threads: value and list slot are used further down)
+        int my_wf = 0, pend_slot = 8, pend_row = -1;
+        R my_val = (R)0;
+        auto flush = [&]() { if (pend_row >= 0 && pend_slot < 8) lfw[(int64_t)pend_row * 8 + pend_slot] = my_wf & 0xffff; };
         for (int base = 0; base < max(nwin, na); base += kThreads) {
             const int j = base + tid;
             const bool row_on = j < nwin;
@@ -686,6 +702,7 @@ template <typename R> struct SparseRecorr {
             const int4* row = reinterpret_cast<const int4*>(lf + (int64_t)g * 8);
             const int4 a = row[0], b = row[1];
             const int wf = na > 0 ? A.nzwf[q] : 0;
+            if (base == 0 && atom_on) { my_wf = wf; my_val = A.nzval[q]; }
             const int fa = wf & 0xffff;
             const int ga = atom_on ? p - P.off + (wf >> 16) : g0;         // inside the window, which is inside the signal
             const int fs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -708,13 +725,18 @@ template <typename R> struct SparseRecorr {
                                     b2.x == fa || b2.y == fa || b2.z == fa || b2.w == fa;
                 if (!listed) {
                     const int o = atomicAdd(&cntw[ga], 1);
-                    if (o < 8) lfw[(int64_t)ga * 8 + o] = fa;
+                    // (the slot number is only needed for the store of the feature index: that store waits until the end
+                    //  of this function, so nobody waits for the atomic's round trip here)
+                    if (base == 0) { pend_slot = o; pend_row = ga; }
+                    else if (o < 8) lfw[(int64_t)ga * 8 + o] = fa;
                 }
             }
         }
+        HSCMP_STAMP(53);
         lds_barrier();
+        HSCMP_STAMP(54);
         const int n0 = L.ctl[0];
-        if (L.ctl[1] > 0 || n0 + na > L.caps.nz || na > kThreads) return false;      // uniform
+        if (L.ctl[1] > 0 || n0 + na > L.caps.nz || na > kThreads) { flush(); return false; }      // uniform
         // Partial sums first (nothing is written to the residual before the form is settled): the span's cells register
         // with partial sum (cell index mod 256); an atom cell that is not in the list yet joins with value 0.
         const int js = s - g0, je = e - g0;                                           // the span's rows inside the window
@@ -725,8 +747,8 @@ template <typename R> struct SparseRecorr {
         {
             const int qa = kThreads - 1 - tid;
             if (qa < na) {                                                           // (na <= 256: one per thread)
-                wfq = A.nzwf[e0 + qa];
-                prod = nc * A.nzval[e0 + qa];                                        // -c*D[k] rounded, then += (utils.py:120,129)
+                wfq = my_wf;
+                prod = nc * my_val;                                                  // -c*D[k] rounded, then += (utils.py:120,129)
                 const int kk = ((wfq & 0xffff) << 16) | (p - P.off + (wfq >> 16) - g0);
                 int jj = n0;
                 for (int j0 = 0; j0 < n0 && jj == n0; j0 += 4) {                    // four list entries per LDS round trip
@@ -738,6 +760,7 @@ template <typename R> struct SparseRecorr {
             }
         }
         lds_barrier();
+        HSCMP_STAMP(55);
         const int n = n0 + L.ctl[2];
         for (int i = tid; i < n; i += kThreads) {
             const int kk = key[i], j = kk & 0xffff;
@@ -747,7 +770,8 @@ template <typename R> struct SparseRecorr {
             if (at == 0) slot0[cq] = i; else if (at == 1) slot1[cq] = i; else L.ctl[3] = 1;
         }
         lds_barrier();
-        if (L.ctl[3] != 0) return false;                                              // uniform; the list appends stay (harmless)
+        HSCMP_STAMP(56);
+        if (L.ctl[3] != 0) { flush(); return false; }                                 // uniform; the list appends stay (harmless)
         // the atom's non-zeros: residual and LDS copy
         if (slot >= 0) {
             const R vn = before[slot] + prod;
@@ -768,6 +792,8 @@ template <typename R> struct SparseRecorr {
             const R sb = b * b, sa = a * a;
             pb = pb + sb; pa = pa + sa;
         }
+        flush();
+        HSCMP_STAMP(57);
         if (tid == 0) { L.ctl[0] = n; L.ctl[3] = -2; }                                 // the window list is ready for run()
         return true;
     }
@@ -1042,6 +1068,12 @@ template <typename R> struct SparseRecorr {
         const R a01 = p[0] + p[1], a23 = p[2] + p[3];
         out = a01 + a23;
         return true;
+    }
+    // After update_residual(): true when merged_update left the updated window in LDS for run() (uniform: the flag is
+    // written before the barriers of the energy tree)
+    static __device__ __forceinline__ bool residual_copy_in_lds(const Args& A0, char* lds)
+    {
+        return A0.rl_cnt && sparse_lds_view<R>(lds, A0.caps).ctl[3] == -2;
     }
     // After run(): the rows p-(W-1) .. p+(W-1) as the arg-max over listed outputs left them in LDS (see sparse_rows, step d)
     static __device__ __forceinline__ bool row_results(const DevParams& P, const Args& A0, char* lds, int p, const int*& rk, const R*& rc,

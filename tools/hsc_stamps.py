@@ -57,6 +57,7 @@ sub = ['gather', 'pairing', 'sort', 'chains', 'row arg-max', 'list append (befor
 for i, nm in enumerate(sub):
     print('    re-correlation / %-14s %9.0f cycles/atom' % (nm, v[40 + i] / n))
 print('    re-correlation / row arg-max: %.0f cycles/atom of it in thread 0\'s own rows, the rest at the barrier' % (v[51] / n))
+print('    residual update (merged form) / first barrier %.0f, gather loop %.0f, barrier %.0f, atom cells + barrier %.0f, partial-sum registration + barrier %.0f, stores + sums %.0f cycles/atom' % tuple(v[52:58] / n))
 cnt = (ctypes.c_ulonglong * 16)()
 lib.hscmp_debug_counters(cnt, 1)
 c = np.array(list(cnt), dtype=np.float64)
