@@ -171,7 +171,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             weights[:nbSingletons] = singletonWeight                   # :1448-1450
             return D, weights, targetSnr, float(np.finfo(D.dtype).eps)
 
-        def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096):
+        def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
             params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
             encode(params)
@@ -190,7 +190,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])
             st, sk, sa = eng.fetch_slots()
             K = eng.K
-            out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+            if lazy:
+                # (the CSC assembly joins the per-signal host epilogue, which runs on all cores)
+                out = [(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+            else:
+                out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
             tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
                       selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()))
             return out, tm
@@ -217,7 +221,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 x = np.ascontiguousarray(np.asarray(sequences).reshape((B, T, -1)), dtype=dt)
                 D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt)
                 engines[0].set_dictionary(D3, np.asarray(weights, dtype=dt))
-                per_level[0], tm = run_level(engines[0], lambda p: engines[0].encode_batch(x, p), B, targetSnr, eps)
+                per_level[0], tm = run_level(engines[0], lambda p: engines[0].encode_batch(x, p), B, targetSnr, eps, lazy=True)
                 tm['level'] = 0
                 timings.append(tm)
                 setups = [None] + [level_setup(l) for l in range(1, nbLevels)]
@@ -239,7 +243,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                         # every input non-zero is explained at least once (by its singleton): size the lists for that
                         nin = int(prev.fetch_stats()[pfirst:pfirst + count, _native.STAT_SLOTS].max())
                         coefs, tm = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
-                                              count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64))
+                                              count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64), lazy=True)
                         per_level[l][first:first + count] = coefs
                         acc = timings[l]
                         acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['chunks'] += 1
@@ -247,7 +251,9 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
         # kernels it spends its time in release the interpreter lock
         def finish(b):
-            cb = self._postprocessCoefficients([per_level[l][b] for l in range(nbLevels)], multilevelDict, returnDistributed)
+            levels = [per_level[l][b] for l in range(nbLevels)]
+            levels = [_slots_to_csc(*c) if isinstance(c, tuple) else c for c in levels]
+            cb = self._postprocessCoefficients(levels, multilevelDict, returnDistributed)
             return cb, self._calculateResidual(sequences[b], cb, multilevelDict)
         workers = max(1, min(16, os.cpu_count() or 1, B))
         if workers > 1:
