@@ -47,6 +47,11 @@ v = np.array(list(out), dtype=np.float64)
 n = max(v[46], 1)
 for tm in timings:
     print('level %d: %-28s init %.2f ms  loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
+nf = max(v[15], 1)
+print('level 0 (fused body), workgroup 0: %d atoms' % nf)
+for i, nm in enumerate(['loads + resolve + update', 'B1', 'energy', 'MFMA tile', 'B4', 'segments + bookkeeping', 'B5', 'deferred stores']):
+    print('  %-28s %9.0f cycles/atom' % (nm, v[i] / nf))
+print('  total %.0f cycles/atom (the selection between atoms is not stamped)' % (v[:8].sum() / nf))
 names = ['select (per round)', 'bookkeeping', 'residual update', 're-correlation', 'segments + stop', '-', '-', 'slow stop rules (per round)']
 print('workgroup 0: %d atoms' % n)
 for i, nm in enumerate(names):
