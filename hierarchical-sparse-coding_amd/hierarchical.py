@@ -255,7 +255,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             levels = [_slots_to_csc(*c) if isinstance(c, tuple) else c for c in levels]
             cb = self._postprocessCoefficients(levels, multilevelDict, returnDistributed)
             return cb, self._calculateResidual(sequences[b], cb, multilevelDict)
-        workers = max(1, min(16, os.cpu_count() or 1, B))
+        workers = max(1, min(int(os.environ.get('HSC_EPILOGUE_WORKERS', '16')), os.cpu_count() or 1, B))
         if workers > 1:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=workers) as pool:
