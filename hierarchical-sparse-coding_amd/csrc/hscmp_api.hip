@@ -399,7 +399,7 @@ static bool use_sparse_init(const hscmp_ctx* ctx, int T)
     return ctx->F > 1 && ctx->d_Dt != nullptr && ctx->W <= 16384 && ctx->F <= 32767 && T <= 262144;
 }
 
-template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)
+template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T, bool packed = false)
 {
     SparseArgs<R> A;
     A.Dt = (const R*)ctx->d_Dt; A.scratch = (R*)ctx->d_scratch;
@@ -408,23 +408,48 @@ template <typename R> static SparseArgs<R> sparse_args(hscmp_ctx* ctx, int T)
     A.nzptr = ctx->d_nzptr; A.nzwf = ctx->d_nzwf; A.nzval = (const R*)ctx->d_nzval;
     A.fptr = getenv("HSCMP_NO_PAIRING") ? nullptr : ctx->d_fptr; A.fkw = ctx->d_fkw; A.fval = (const R*)ctx->d_fval;
     A.nnz = ctx->dict_nnz; A.wts = (const R*)ctx->d_w;
-    A.caps = sparse_caps(ctx->W);
+    A.caps = sparse_caps(ctx->W, packed);
     const bool lists = use_row_lists(ctx) && ctx->d_rl_cnt != nullptr;
     A.rl_cnt = lists ? ctx->d_rl_cnt : nullptr; A.rl_f = ctx->d_rl_f; A.rl_cap = kRowListCap; A.rl_filled = ctx->rl_filled ? 1 : 0;
     return A;
 }
 
-template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const DevParams& P0)
+// More signals than two per CU: the four-workgroups-per-CU form of the loop (see SparseRecorr) when its LDS fits.
+static bool sparse_loop_packed(const DevParams& P, size_t lds_packed)
 {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    if (getenv("HSCMP_SPARSE_PACKED")) return atoi(getenv("HSCMP_SPARSE_PACKED")) != 0;
+    return P.B > 2 * cus && lds_packed <= (size_t)40 * 1024;
+}
+
+template <typename R, bool PACKED> static int launch_iterate_sparse_t(hscmp_ctx* ctx, const DevParams& P0, bool dry, size_t* lds_out)
+{
+    using Pol = SparseRecorr<R, PACKED>;
     State<R> S = make_state<R>(ctx);
     DevParams P = P0;
-    set_segments(P, SparseRecorr<R>::kMaxSegments);
-    const SparseArgs<R> A = sparse_args<R>(ctx, P.T);
-    const size_t lds = ((sizeof(typename SparseRecorr<R>::Shared) + 15) / 16) * 16 + SparseRecorr<R>::extra_lds_bytes(P, A);
-    auto kern = iterate_kernel<R, SparseRecorr<R>>;
+    set_segments(P, Pol::kMaxSegments);
+    const SparseArgs<R> A = sparse_args<R>(ctx, P.T, PACKED);
+    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    if (lds_out) *lds_out = lds;
+    if (dry) return HSCMP_OK;
+    auto kern = iterate_kernel<R, Pol>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
+}
+
+template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const DevParams& P0)
+{
+    size_t lds_packed = 0;
+    (void)launch_iterate_sparse_t<R, true>(ctx, P0, true, &lds_packed);
+    if (sparse_loop_packed(P0, lds_packed)) return launch_iterate_sparse_t<R, true>(ctx, P0, false, nullptr);
+    return launch_iterate_sparse_t<R, false>(ctx, P0, false, nullptr);
 }
 
 template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const DevParams& P)

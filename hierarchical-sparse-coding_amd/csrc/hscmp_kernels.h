@@ -625,6 +625,8 @@ __device__ __forceinline__ R wave_window_energy(const DevParams& P, const Sig<R>
 template <typename R> struct GenericRecorr {
     static constexpr int kMaxSegments = kMaxSeg;
     static constexpr bool kFused = false;               // uses the step-by-step atom body of iterate_kernel
+    static constexpr int kMinWavesPerSimd = 1;          // (register budget: no constraint)
+    static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = false;           // keeps (coefficient, atom) per position
     using Shared = IterSharedT<R, kMaxSeg>;
     struct Args {};                                     // no extra kernel arguments
@@ -723,7 +725,7 @@ template <typename R> struct GenericRecorr {
 // the greedy loop            grid = B, block = kThreads, one persistent workgroup per signal
 // ------------------------------------------------------------------------------------------------
 template <typename R, typename Recorr>
-__global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
+__global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
 {
     // all LDS comes from ONE dynamic array (16-byte aligned base): control block first, then the
     // policy's region (dictionary image, residual window)
@@ -902,14 +904,22 @@ __global__ __launch_bounds__(kThreads) void iterate_kernel(DevParams P, State<R>
                 } else {
                     // long windows (multi-feature inputs).  A policy that knows which cells can be non-zero gives every
                     // wave its own candidates first (flag -1: not settled that way) ...
-                    for (int i = wv; i < n; i += kWaves) {
-                        int len, ws, we, wes;
-                        len = centered_span(T, W, ord_t[i], ws, we, wes);
-                        R e = (R)0;
-                        const bool done = len > 0 && Recorr::wave_window_listed(P, G, A, plds, ws, we, lane, wv, e);
-                        if (lane == 0) {
-                            const R mean = e / (R)((int64_t)len * F);
-                            raw_t[i] = !done ? -1 : ((double)mean >= thr) ? 1 : 0;
+                    // (a policy whose LDS table holds fewer than four windows lets the waves in by turns)
+                    constexpr int kEW = Recorr::kEnergyWaves;
+                    for (int i0 = 0; i0 < n; i0 += kWaves) {
+                        for (int turn = 0; turn < kWaves / kEW; ++turn) {
+                            const int i = i0 + wv;
+                            if (wv / kEW == turn && i < n) {
+                                int len, ws, we, wes;
+                                len = centered_span(T, W, ord_t[i], ws, we, wes);
+                                R e = (R)0;
+                                const bool done = len > 0 && Recorr::wave_window_listed(P, G, A, plds, ws, we, lane, wv % kEW, e);
+                                if (lane == 0) {
+                                    const R mean = e / (R)((int64_t)len * F);
+                                    raw_t[i] = !done ? -1 : ((double)mean >= thr) ? 1 : 0;
+                                }
+                            }
+                            if (kEW < kWaves) lds_barrier();
                         }
                     }
                     __syncthreads();

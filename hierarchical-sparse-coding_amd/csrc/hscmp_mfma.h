@@ -545,6 +545,8 @@ template <typename R> inline bool mfma_supported(int K, int W, int F)
 template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
+    static constexpr int kMinWavesPerSimd = 1;
+    static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = true;    // best_c[t] holds max_k |c[t,k]*w_k|; (k, c) resolved on selection
     static constexpr int kBook = 192;           // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
     using R = typename Tile::R;

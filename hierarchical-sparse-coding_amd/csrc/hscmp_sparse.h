@@ -37,15 +37,18 @@ struct SparseCaps {
     int nz;     // gathered non-zeros of the window
     int rec;    // (input non-zero, dictionary non-zero) pairs; nz <= rec <= 1024 (10-bit index in the row arg-max)
     int rows;   // occupied rows of the window (also the largest row count the bucketed pair sort handles)
+    int ewaves; // waves that take weak-atom-filter energies at the same time (SparseRecorr::wave_window_listed's table)
 };
-inline SparseCaps sparse_caps(int W)
+inline SparseCaps sparse_caps(int W, bool packed = false)
 {
     // a window spans 3W-2 rows; room for about 2 input non-zeros and 8 pairs per row, within 128..512 / 256..1024
+    // (packed: the four-workgroups-per-CU form of the loop, half the pair capacity -- overflows take the per-atom chains)
     auto pow2 = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
     SparseCaps c;
     c.nz = std::min(512, std::max(128, pow2(2 * (3 * W - 2))));
-    c.rec = std::min(1024, std::max(256, pow2(8 * (3 * W - 2))));
+    c.rec = std::min(1024, std::max(256, pow2((packed ? 4 : 8) * (3 * W - 2))));
     c.rows = 256;
+    c.ewaves = packed ? kWaves / 2 : kWaves;
     return c;
 }
 constexpr int kDictListMaxPerAtom = 32; // a dictionary with at most this many non-zeros per atom (average) gets per-atom lists
@@ -151,7 +154,7 @@ template <typename R> struct SparseLds {
 __host__ __device__ inline size_t sparse_lds_bytes_of(const SparseCaps& c, size_t es)
 {
     size_t b = 16 + (size_t)c.nz * (es + 4) + (size_t)(c.rows + 1) * 8 + 8 + (size_t)c.rec * (8 + 3 * es + 8);
-    const size_t wave_energy = (size_t)kWaves * kThreads * (2 * es + 4);     // SparseRecorr::wave_window_listed borrows the region
+    const size_t wave_energy = (size_t)c.ewaves * kThreads * (2 * es + 4);       // SparseRecorr::wave_window_listed borrows the region
     if (b < wave_energy) b = wave_energy;
     return (b + 15) / 16 * 16;
 }
@@ -610,10 +613,15 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
 // ------------------------------------------------------------------------------------------------
 // policy of iterate_kernel: local re-correlation of the 2W-1 touched rows, reflect padded
 // ------------------------------------------------------------------------------------------------
-template <typename R> struct SparseRecorr {
+// PACKED: the same loop compiled for four workgroups per CU (128 VGPRs -- it spills --, half the segment table): the loop
+// is latency-bound and co-resident workgroups overlap perfectly, so a batch of more than 2 x CUs signals finishes in
+// fewer rounds; smaller batches run the roomier form.
+template <typename R, bool PACKED = false> struct SparseRecorr {
     // LDS per workgroup is kept near 40 KB (4 workgroups per CU): the loop is latency bound, not compute bound
-    static constexpr int kMaxSegments = 512;
+    static constexpr int kMaxSegments = PACKED ? 256 : 512;
     static constexpr bool kFused = false;
+    static constexpr int kMinWavesPerSimd = PACKED ? 4 : 1;
+    static constexpr int kEnergyWaves = PACKED ? kWaves / 2 : kWaves;
     static constexpr bool kScoreOnly = false;
     using Shared = IterSharedT<R, kMaxSegments, false>;
     using Args = SparseArgs<R>;
@@ -1023,9 +1031,10 @@ template <typename R> struct SparseRecorr {
         const int T = P.T, F = P.F;
         const int* cnt = A0.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A0.rl_f + (int64_t)blockIdx.x * T * 8;
-        R* first = reinterpret_cast<R*>(lds) + (size_t)wv * kThreads;                       // [kWaves][256]
-        R* second = reinterpret_cast<R*>(lds) + (size_t)(kWaves + wv) * kThreads;           // [kWaves][256]
-        int* members = reinterpret_cast<int*>(lds + (size_t)2 * kWaves * kThreads * sizeof(R)) + (size_t)wv * kThreads;
+        // (wv < kEnergyWaves: the caller lets the waves in by turns when the table holds fewer than four windows)
+        R* first = reinterpret_cast<R*>(lds) + (size_t)wv * kThreads;                       // [kEnergyWaves][256]
+        R* second = reinterpret_cast<R*>(lds) + (size_t)(kEnergyWaves + wv) * kThreads;     // [kEnergyWaves][256]
+        int* members = reinterpret_cast<int*>(lds + (size_t)2 * kEnergyWaves * kThreads * sizeof(R)) + (size_t)wv * kThreads;
 #pragma unroll
         for (int c = 0; c < 4; ++c) members[lane + 64 * c] = 0;
         bool bad = false;                                   // (one wave: its LDS operations execute in order)

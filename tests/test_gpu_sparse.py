@@ -12,7 +12,8 @@ VARIANTS = {'paired': {}, 'atom_lists': {'HSCMP_NO_PAIRING': '1'},
             'gathered': {'HSCMP_NO_DICT_LISTS': '1', 'HSCMP_FORCE_GATHERED': '1'},
             'dense_dictionary': {'HSCMP_NO_DICT_LISTS': '1'},        # sparse initial correlation + dense LDS-staged loop
             'paired_row_scan': {'HSCMP_NO_ROW_LISTS': '1'},
-            'paired_no_rowbits': {'HSCMP_NO_ROW_LISTS': '1', 'HSCMP_NO_ROWBITS': '1'}}
+            'paired_no_rowbits': {'HSCMP_NO_ROW_LISTS': '1', 'HSCMP_NO_ROWBITS': '1'},
+            'packed': {'HSCMP_SPARSE_PACKED': '1'}}            # the four-workgroups-per-CU build of the loop (batches > 2 x CUs)
 
 
 def _level_case(seed, T, F, K, W, dtype, nnz_atom=3, density=0.02, singletons=True):
@@ -106,6 +107,7 @@ def test_variants_are_the_ones_dispatched(monkeypatch):
     assert names['dense_dictionary'].startswith('sparse_init+generic_loop')
     assert names['paired_no_rowbits'].startswith('dictlist_init+dictlist_loop')
     assert names['paired_row_scan'].startswith('dictlist_init+dictlist_loop')
+    assert names['packed'].startswith('dictlist_init+dictlist_loop')
 
 
 def test_dense_level_dictionary_takes_the_dense_loop():
