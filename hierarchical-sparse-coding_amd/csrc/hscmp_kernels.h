@@ -72,7 +72,10 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
     bool over = false;
     if (tid == 0) overflow = 0;
     __syncthreads();
-    const bool crowded = rl_cnt && rl_cap == 8 && n > 48 * kThreads;      // bound to overflow: go to the row lists at once
+    // bound to overflow: go to the row lists at once.  With many workgroups in flight the walk (latency-bound, about as
+    // long per workgroup whatever n) also beats the private lists much earlier (their insertion sort lives in scratch
+    // memory: 21 vs 11 ms for 1024 signals of 8.5 k cells; 64 signals: 0.3 ms the other way round).
+    const bool crowded = rl_cnt && rl_cap == 8 && (n > 48 * kThreads || (n > 16 * kThreads && gridDim.x > 512));
     if (crowded && tid == 0) overflow = 1;
     for (int i = 0; i < (crowded ? 0 : n); ++i) {   // (all threads read the same entries: broadcast loads)
         const double a = slot_a[(int64_t)src * pcap + i];
