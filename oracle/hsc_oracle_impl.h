@@ -19,6 +19,10 @@ static void SFX(row_chains)(const REAL* win, const REAL* Dt, int K, int W, int F
     for (int f = 0; f < F; ++f)
         for (int w = 0; w < W; ++w) {
             const REAL xv = win[w * F + f];
+            /* a zero sample leaves every chain as it is: fma(+-0, d, acc) == acc for finite d (acc starts at +0 and a
+             * round-to-nearest sum never yields -0 from it), so the step is skipped.  The chain ORDER is unchanged;
+             * this only makes the almost-all-zero inputs of the hierarchical levels >= 1 (modeling.py:1489) affordable. */
+            if (xv == (REAL)0) continue;
             const REAL* d = Dt + (int64_t)(f * W + w) * K;
             for (int k = 0; k < K; ++k) acc[k] = RFMA(xv, d[k], acc[k]);
         }

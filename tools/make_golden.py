@@ -20,6 +20,8 @@ Files written:
                                    its window-assignment step (convolve1d_batch + arg-max) on fixed windows
   tests/golden/hsc_medium.npz   -- 2-level hierarchical encoder on generated data (8192 samples, level-1 dictionary
                                    (24+20) x 33 x 24): per-level coefficients of the reference, inputs by seed
+  tests/golden/hsc_config4.npz  -- 2-level hierarchical encoder at the BASELINE config-4 dictionary dimensions ((256+128) x 16|17 x 256),
+                                   8192 samples; reconstructSignal's dense (fftconvolve) branch on small seeded cases
   tests/golden/hsc_small.npz    -- 3-level hierarchical encoder (method='cmp'): dictionaries with
                                    singleton bases, representations, per-level coefficients, residual
 """
@@ -363,6 +365,49 @@ def gen_hsc_medium():
     print('wrote hsc_medium.npz', os.path.getsize(os.path.join(OUT, 'hsc_medium.npz')), 'bytes')
 
 
+def gen_hsc_config4():
+    """Hierarchical encoder of the REAL reference at the dictionary dimensions of BASELINE config 4 (level 0: 256 x 64,
+    level 1: (256 singletons + 128) x W1 x 256; hsc_amd.synth.make_hierarchy), one 8192-sample signal per case: W1=16 is the
+    exact shape, W1=17 the nearest one whose hierarchy reconstructs (see make_hierarchy).  Inputs are regenerated by the
+    tests from the seeds; digests and the reference's coefficients are stored.  Also: reconstructSignal's DENSE branch
+    (modeling.py:247-258, fftconvolve) on a small seeded case, which the engine answers by overlap-add."""
+    import copy
+    ref = load_reference()
+    out = {}
+    kw = dict(toleranceSnr=[30.0, 40.0], nbBlocks=10, singletonWeight=0.95)
+    for W1 in (16, 17):
+        D0, decompositions, scales = synth.make_hierarchy_parts(W1=W1, seed=4)
+        mld = ref.dataset.MultilevelDictionary.fromDecompositions(D0, copy.deepcopy(decompositions), np.array(scales))
+        own = synth.make_hierarchy(W1=W1, seed=4)
+        x = synth.make_hierarchy_signal(own, 8192, 0, seed=4)
+        out['w%d__x_digest' % W1] = np.array(synth.digest(x))
+        out['w%d__dict_digest' % W1] = np.array(synth.digest(*own.withSingletonBases().dictionaries))
+        mlds = mld.withSingletonBases()
+        assert all(np.array_equal(a, b) for a, b in zip(mlds.dictionaries, own.withSingletonBases().dictionaries))
+        t0 = time.time()
+        hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mlds, ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='cmp'))
+        coefficients, residual = hcsc.encode(x, **kw)
+        for l, c in enumerate(coefficients):
+            pack_csc('w%d__level%d' % (W1, l), scipy_sparse(c), out)
+        e = float(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
+        out['w%d__residual_energy' % W1] = np.float64(e)
+        print('hsc_config4 W1=%d' % W1, [c.nnz for c in coefficients], 'SNR %.2f dB' % (10 * np.log10(np.sum(x.astype(np.float64) ** 2) / e)),
+              '%.1f s' % (time.time() - t0))
+    # dense branch of reconstructSignal
+    rs = np.random.RandomState(20261004)
+    for name, (T, K, W, F) in (('dense1d', (96, 5, 8, 1)), ('dense1d_odd', (80, 4, 9, 1)), ('dense2d', (64, 3, 6, 4))):
+        D = rs.standard_normal((K, W) if F == 1 else (K, W, F))
+        C = np.zeros((T, K))
+        for _ in range(12):
+            C[rs.randint(0, T), rs.randint(0, K)] = rs.uniform(-2, 2)
+        out['%s__D' % name] = D; out['%s__C' % name] = C
+        out['%s__signal' % name] = np.asarray(ref.modeling.reconstructSignal(C, D))
+        import scipy.sparse
+        out['%s__signal_sparse' % name] = np.asarray(ref.modeling.reconstructSignal(scipy.sparse.csc_matrix(C), D))
+    np.savez_compressed(os.path.join(OUT, 'hsc_config4.npz'), **out)
+    print('wrote hsc_config4.npz', os.path.getsize(os.path.join(OUT, 'hsc_config4.npz')), 'bytes')
+
+
 def gen_locomp():
     """LoCOMP (modeling.py:1191-1425) on small seeded problems."""
     ref = load_reference()
@@ -510,7 +555,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'locomp', 'synth', 'learn']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'hsc4', 'locomp', 'synth', 'learn']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -521,6 +566,8 @@ if __name__ == '__main__':
         gen_hsc()
     if 'hscmed' in which:
         gen_hsc_medium()
+    if 'hsc4' in which:
+        gen_hsc_config4()
     if 'locomp' in which:
         gen_locomp()
     if 'synth' in which:
