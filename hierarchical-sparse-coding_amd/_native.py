@@ -297,6 +297,16 @@ class Engine(object):
         self._check(self._lib.hscmp_fetch_events(self._h, _ptr(t), _ptr(k), _ptr(c)), 'hscmp_fetch_events')
         return t, k, c
 
+    # raw-pointer forms (pinned host buffers owned by the caller, e.g. bench.py's PCIe-inclusive leg)
+    def fetch_events_into(self, t_ptr, k_ptr, c_ptr):
+        self._check(self._lib.hscmp_fetch_events(self._h, ctypes.c_void_p(t_ptr), ctypes.c_void_p(k_ptr), ctypes.c_void_p(c_ptr)), 'hscmp_fetch_events')
+
+    def fetch_stats_into(self, ptr):
+        self._check(self._lib.hscmp_fetch_stats(self._h, ctypes.c_void_p(ptr)), 'hscmp_fetch_stats')
+
+    def fetch_energies_into(self, ptr):
+        self._check(self._lib.hscmp_fetch_energies(self._h, ctypes.c_void_p(ptr)), 'hscmp_fetch_energies')
+
     def fetch_slots(self):
         B, _, cap = self._batch
         t = np.empty((B, cap), dtype=np.int32)

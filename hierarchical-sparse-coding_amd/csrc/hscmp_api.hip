@@ -65,6 +65,7 @@ struct hscmp_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
+    bool mfma_state = false;        // the batch's table-free state is the score-only form of the MFMA kernels
 };
 
 static thread_local std::string g_err;
@@ -490,11 +491,17 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     else
         hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // The matrix-core kernels come as a pair: the score-only state the initial correlation leaves is what the MFMA loop
+    // reads (the generic / sparse kernels keep coefficient + atom instead).  Both are configured before anything is
+    // queued; if either cannot run this shape, neither does.
     bool mf = false;
-    if (use_mfma(ctx, P.T)) {
-        int rc = mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
-        if (rc == 0) mf = true;
+    if (use_mfma(ctx, P.T) && mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag, true) == 0 &&
+        mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag, true) == 0) {
+        if (mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag) != 0)
+            return fail(ctx, HSCMP_ERR_HIP, "the MFMA initial correlation could not be launched");
+        mf = true;
     }
+    ctx->mfma_state = mf;
     if (!mf && use_sparse_loop(ctx) && use_row_lists(ctx) && !ctx->rl_filled) {
         // per-row lists of the input's non-zero cells (the level chaining writes them while it scatters)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_cnt, 0, (size_t)P.B * P.T * sizeof(int), ctx->stream));
@@ -512,9 +519,10 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     bool mfi = false;
-    if (use_mfma(ctx, P.T)) {
-        int rc = mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
-        if (rc == 0) mfi = true;
+    if (mf) {
+        if (mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag) != 0)
+            return fail(ctx, HSCMP_ERR_HIP, "the MFMA loop could not be launched on the state of the MFMA initial correlation");
+        mfi = true;
     }
     const bool spl = !mfi && use_sparse_loop(ctx);
     if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
@@ -523,7 +531,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
     ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
-                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64");
+                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + (mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
     return HSCMP_OK;
 }
 
@@ -611,14 +619,17 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
     bool mfi = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));       // hscmp_last_kernel_ms: [2] = this launch, [0] = [1] = 0
     ctx->timed_loop_only = true;
-    if (use_mfma(ctx, P.T)) {
+    if (ctx->mfma_state) {          // the loop must be the one that understands the state the encode left
+        int rc;
         if (ctx->dtype == HSCMP_F32) {
             State<float> S = make_state<float>(ctx);
-            if (mfma_launch_iterate<float>(ctx->stream, P, S, (const float*)ctx->d_Dfrag) == 0) mfi = true;
+            rc = mfma_launch_iterate<float>(ctx->stream, P, S, (const float*)ctx->d_Dfrag);
         } else {
             State<double> S = make_state<double>(ctx);
-            if (mfma_launch_iterate<double>(ctx->stream, P, S, (const double*)ctx->d_Dfrag) == 0) mfi = true;
+            rc = mfma_launch_iterate<double>(ctx->stream, P, S, (const double*)ctx->d_Dfrag);
         }
+        if (rc != 0) return fail(ctx, HSCMP_ERR_HIP, "hscmp_continue: the MFMA loop could not be launched");
+        mfi = true;
     }
     if (!mfi && use_sparse_loop(ctx)) {
         int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);

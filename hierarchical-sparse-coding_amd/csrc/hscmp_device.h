@@ -41,6 +41,67 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Synchronisation of the threads that work on ONE signal.
+//   HwSync    the signal owns the whole 256-thread workgroup: the hardware barrier.
+//   SoftSync  several signals share one workgroup (hscmp_mfma.h, four signals per 1024-thread workgroup: one
+//             dictionary image per CU, four waves per SIMD): s_barrier would put the signals in lockstep, so the four
+//             waves of a signal meet at a monotone counter in LDS instead.  One lane per wave adds 1; the wave then
+//             polls until the counter reaches 4 x (barriers passed).  The LDS executes the operations of a wave in
+//             issue order, so everything a wave wrote (or read) before its add is done before a wave that has seen the
+//             add issues its next access: no s_waitcnt is needed for LDS data.  full() also drains the wave's global
+//             stores / loads (s_waitcnt vmcnt(0)) before the add, as __syncthreads() does: the waves of a workgroup
+//             share the CU's write-through vector cache.
+// Every wave of the group must pass the same sequence of barriers.
+// ------------------------------------------------------------------------------------------------
+struct HwSync {
+    static constexpr int kGroup = 1;
+    __device__ __forceinline__ void lds() { lds_barrier(); }
+    __device__ __forceinline__ void full() { __syncthreads(); }
+    __device__ __forceinline__ int count(int pred) { return __syncthreads_count(pred); }
+};
+
+struct SoftSync {
+    static constexpr int kGroup = 4;
+    unsigned* bar;        // LDS: arrivals so far (monotone; compared modulo 2^32)
+    int* cnt;             // LDS: scratch of count()
+    unsigned target;      // 4 x barriers passed by this wave (wave-uniform)
+    __device__ __forceinline__ void arrive_and_wait()
+    {
+        target += 4u;
+        asm volatile("" ::: "memory");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if ((int)(v - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void lds() { arrive_and_wait(); }
+    __device__ __forceinline__ void full()
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrive_and_wait();
+    }
+    // number of threads of the group whose predicate holds (as __syncthreads_count)
+    __device__ __forceinline__ int count(int pred)
+    {
+        const int n = __popcll(__ballot(pred != 0));
+        if ((threadIdx.x & 255) == 0) *cnt = 0;
+        full();
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(cnt, n);
+        lds();
+        const int total = *cnt;
+        lds();                  // everybody has read the total before the next count() resets it
+        return total;
+    }
+};
+
+// index of a thread inside the 256 threads that work on its signal (256-thread kernels: threadIdx.x itself; the
+// compiler knows the range from __launch_bounds__ and drops the mask)
+__device__ __forceinline__ int ltid() { return (int)(threadIdx.x & 255u); }
+
 constexpr int kEdgeWords = 4;    // per signal: left mask, right mask, stale sample index + 1 (0: none), its saved bits
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
 constexpr int kWaves = kThreads / 64;
@@ -68,6 +129,8 @@ struct DevParams {
     unsigned hmask;     // slots of the per-signal (t,k) -> coefficient-slot hash table, minus one (power of two >= 2*cap)
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
+    int cus;            // compute units of the device (start stagger of co-resident workgroups)
+    int stagger;        // cycles by which consecutive signals of one workgroup start apart (kGroup > 1 policies)
 };
 
 // table size of the slot hash: load factor <= 1/2 whatever the event list holds
@@ -187,7 +250,7 @@ template <typename R> __device__ __forceinline__ R wave_max(R v)
 // Pinned summation tree (DESIGN.md "Numerics", oracle hsco_energy_*): the caller has formed the
 // 256 strided partials p[tid]; halving tree inside each wave, then (P0+P1)+(P2+P3).
 // Returns the total in thread 0 (other threads: unspecified).  `scratch` holds >= 2*kWaves R's.
-template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch)
+template <typename R, typename SY> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch, SY& sy)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -196,11 +259,11 @@ template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R
         a = a + oa;
         b = b + ob;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    lds_barrier();                                      // (scratch lives in LDS: no need to drain global stores here)
+    const int lane = ltid() & 63, wv = ltid() >> 6;
+    sy.lds();                                           // (scratch lives in LDS: no need to drain global stores here)
     if (lane == 0) { scratch[wv] = a; scratch[kWaves + wv] = b; }
-    lds_barrier();
-    if (threadIdx.x == 0) {
+    sy.lds();
+    if (ltid() == 0) {
         R a01 = scratch[0] + scratch[1];
         R a23 = scratch[2] + scratch[3];
         a = a01 + a23;
@@ -208,6 +271,11 @@ template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R
         R b23 = scratch[kWaves + 2] + scratch[kWaves + 3];
         b = b01 + b23;
     }
+}
+template <typename R> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch)
+{
+    HwSync hw;
+    pinned_tree2(a, b, scratch, hw);
 }
 
 // utils.py:76-161: clipped support [s,e) of a width-W element centred at t, element offset es

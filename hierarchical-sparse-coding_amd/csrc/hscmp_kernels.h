@@ -357,6 +357,8 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     int sel_t[2 * kSelLds]; int sel_k[2 * kSelLds]; R sel_c[2 * kSelLds];
     Cand<R> cred[kWaves];
     int wtot[kWaves];
+    unsigned bar;             // SoftSync: arrivals at the signal's barrier (several signals per workgroup)
+    int bar_cnt;              // SoftSync::count scratch
     // control block (written by thread 0, read by all after a barrier)
     int nsel, converged, stop, found, skip;
     int nullsel;              // a fused atom body found the selected coefficient null (:974): the round selected nothing
@@ -428,11 +430,11 @@ template <typename R> __device__ __forceinline__ void slot_insert_at(const Sig<R
 }
 // table of the first `nslots` slots, by the whole workgroup (the slot list must be visible: call after a full
 // barrier; the caller ends with one as well)
-template <typename R> __device__ __forceinline__ void slot_table_build(const Sig<R>& G, unsigned hmask, int nslots)
+template <typename R, typename SY> __device__ __forceinline__ void slot_table_build(const Sig<R>& G, unsigned hmask, int nslots, SY& sy)
 {
-    for (unsigned i = threadIdx.x; i <= hmask; i += kThreads) hkey_store(G.hkey + i, kSlotEmpty);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nslots; i += kThreads) slot_insert(G, hmask, G.slot_t[i], G.slot_k[i], i);
+    for (unsigned i = ltid(); i <= hmask; i += kThreads) hkey_store(G.hkey + i, kSlotEmpty);
+    sy.full();
+    for (int i = ltid(); i < nslots; i += kThreads) slot_insert(G, hmask, G.slot_t[i], G.slot_k[i], i);
 }
 
 // arg-max of the per-position best over positions [t0,t1) by one wave; result in all lanes.
@@ -539,20 +541,20 @@ __device__ __forceinline__ void rscan_segment(const DevParams& P, const Sig<R>& 
 }
 
 // block-wide stable compaction of list entries [0,n) with predicate pred(i): src -> dst; returns count
-template <typename R, typename SH, typename Pred>
+template <typename R, typename SH, typename Pred, typename SY>
 __device__ __forceinline__ int block_compact(int n, Pred pred, const int* st, const int* sk, const R* sc,
-                                              int* dt, int* dk, R* dc, SH& sh)
+                                              int* dt, int* dk, R* dc, SH& sh, SY& sy)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
     int running = 0;
     for (int base = 0; base < n; base += kThreads) {
         const int i = base + tid;
         const int f = (i < n) ? (pred(i) ? 1 : 0) : 0;
         const unsigned long long mask = __ballot(f);
         const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        __syncthreads();
+        sy.full();
         if (lane == 0) sh.wtot[wv] = __popcll(mask);
-        __syncthreads();
+        sy.full();
         int before = 0, total = 0;
 #pragma unroll
         for (int q = 0; q < kWaves; ++q) { const int c = sh.wtot[q]; if (q < wv) before += c; total += c; }
@@ -562,13 +564,13 @@ __device__ __forceinline__ int block_compact(int n, Pred pred, const int* st, co
         }
         running += total;
     }
-    __syncthreads();
+    sy.full();
     return running;
 }
 
 // energy of the clipped window centred at t, pinned order; result valid in thread 0
-template <typename R, typename SH>
-__device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R>& G, SH& sh, int t, int& len)
+template <typename R, typename SH, typename SY>
+__device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R>& G, SH& sh, int t, int& len, SY& sy)
 {
     int s, e, es;
     len = centered_span(P.T, P.W, t, s, e, es);
@@ -577,7 +579,7 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
         const int n = len * P.F;
         const R* v = G.r + (int64_t)s * P.F;
         constexpr int kU = 8;                      // loads of a batch issued together
-        for (int i0 = threadIdx.x; i0 < n; i0 += kThreads * kU) {
+        for (int i0 = ltid(); i0 < n; i0 += kThreads * kU) {
             R x[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) { const int i = i0 + u * kThreads; x[u] = i < n ? v[i] : (R)0; }
@@ -585,7 +587,7 @@ __device__ __forceinline__ R block_window_energy(const DevParams& P, const Sig<R
             for (int u = 0; u < kU; ++u) { if (i0 + u * kThreads < n) { const R sq = x[u] * x[u]; p = p + sq; } }
         }
     }
-    pinned_tree2(p, q, sh.red);
+    pinned_tree2(p, q, sh.red, sy);
     return p;
 }
 
@@ -633,7 +635,12 @@ template <typename R> struct GenericRecorr {
     static constexpr bool kScoreOnly = false;           // keeps (coefficient, atom) per position
     using Shared = IterSharedT<R, kMaxSeg>;
     struct Args {};                                     // no extra kernel arguments
-    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*) {}
+    static constexpr int kGroup = 1;                    // signals per workgroup
+    using Sync = HwSync;
+    static __device__ __forceinline__ Sync make_sync(Shared&) { return Sync(); }
+    static __device__ __forceinline__ void prologue_shared(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __device__ __forceinline__ int signal_lds_offset(const DevParams&, const Args&) { return 0; }
+    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*, int) {}
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*,
                                                         int, int, int&, R&) {}
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
@@ -646,7 +653,7 @@ template <typename R> struct GenericRecorr {
     static __device__ __forceinline__ bool residual_copy_in_lds(const Args&, char*) { return false; }
     static constexpr int kWinBytes = 16384;            // LDS window of the residual span, when it fits
     static size_t extra_lds_bytes(const DevParams&) { return kWinBytes; }
-    static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __device__ __forceinline__ void prologue(const DevParams&, const State<R>&, const Args&, char*, int, Sync&) {}
     template <typename SH>
     static __device__ __forceinline__ void run(const DevParams& P, const State<R>& S, const Sig<R>& G,
                                                SH& sh, const Args&, char* lds, int p, int)
@@ -725,18 +732,29 @@ template <typename R> struct GenericRecorr {
 };
 
 // ------------------------------------------------------------------------------------------------
-// the greedy loop            grid = B, block = kThreads, one persistent workgroup per signal
+// the greedy loop            grid = ceil(B / kGroup), block = kGroup * kThreads
+//   256 threads (4 waves) work on one signal from its first selection to its last.  kGroup = 1: the signal owns
+//   the workgroup.  kGroup = 4 (hscmp_mfma.h): four signals share a 1024-thread workgroup and ONE dictionary
+//   image in LDS; each signal synchronises its own four waves (SoftSync), the signals never wait for each other.
 // ------------------------------------------------------------------------------------------------
 template <typename R, typename Recorr>
-__global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
+__global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
 {
-    // all LDS comes from ONE dynamic array (16-byte aligned base): control block first, then the
-    // policy's region (dictionary image, residual window)
+    // all LDS comes from ONE dynamic array (16-byte aligned base): per signal the control block first, then the
+    // policy's region (dictionary image, residual window); a policy with kGroup > 1 keeps what the signals share
+    // in front of the per-signal regions
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using SH = typename Recorr::Shared;
-    SH& sh = *reinterpret_cast<SH*>(smem);
-    char* plds = smem + ((sizeof(SH) + 15) / 16) * 16;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int GS = Recorr::kGroup;
+    Recorr::prologue_shared(P, S, A, smem);              // (kGroup > 1: the shared image, behind a hardware barrier)
+    // (wave-uniform by construction; readfirstlane tells the compiler, so the per-signal pointers live in SGPRs)
+    const int b = GS == 1 ? (int)blockIdx.x : (int)blockIdx.x * GS + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    if (GS > 1 && b >= P.B) return;                      // (a ragged last workgroup; no hardware barrier from here on)
+    char* sbase = smem + Recorr::signal_lds_offset(P, A);
+    SH& sh = *reinterpret_cast<SH*>(sbase);
+    char* plds = sbase + ((sizeof(SH) + 15) / 16) * 16;
+    const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
+    typename Recorr::Sync sy = Recorr::make_sync(sh);
     int* stats = S.stats + (int64_t)b * ST_COUNT;
     if (stats[ST_STOP] != STOP_RUNNING) return;          // converged in an earlier launch
 
@@ -758,7 +776,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
         g_blk[3 * b + 2] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
-    Recorr::prologue(P, S, A, plds);
+    Recorr::prologue(P, S, A, plds, b, sy);
     const R* wts = Recorr::weights(P, S, A, plds);        // atom weights (a policy may keep a copy in LDS)
 
     // ---- prologue: segment maxima of the per-position best (and of |residual|)
@@ -774,14 +792,14 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
         for (int i = tid; i < (Recorr::kMaxSegments + 31) / 32; i += kThreads) sh.touched[i] = 0u;
         // Bloom filter over the (t,k) pairs that already own a coefficient slot (rebuilt on every launch)
         for (int i = tid; i < kBloomWords; i += kThreads) sh.bloom[i] = 0u;
-        __syncthreads();
+        sy.full();
         const int ns = stats[ST_SLOTS];
         for (int i = tid; i < ns; i += kThreads) {
             const unsigned h = bloom_hash(G.slot_t[i], G.slot_k[i]);
             atomicOr(&sh.bloom[h >> 5], 1u << (h & 31));
         }
     }
-    __syncthreads();
+    sy.full();
 
     // candidate lists of a round: LDS when they fit (the compactions and sorts of the blocked selection are a chain
     // of dependent passes over them), else the per-signal global buffers; the select-only entry point hands the
@@ -791,6 +809,23 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
     int* ord_t = raw_t + P.maxsel; int* ord_k = raw_k + P.maxsel; R* ord_c = raw_c + P.maxsel;                                      // second half
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
+
+    // Signals that share a workgroup run the same program on the same SIMDs: started together they stay in lockstep
+    // (the matrix pipe is shared fairly, so they finish their tiles together and then all sit in their serial phases
+    // together, with the pipe idle).  The phase offset a signal starts with persists, so signal i of the workgroup is
+    // held back by i tile times: while one signal selects / updates, the tiles of the others keep the pipe busy.
+    if constexpr (GS > 1) {
+        const int slot = b - (int)blockIdx.x * GS;
+        const int naps = (slot * P.stagger + 8127) / 8128;              // s_sleep 127 = 127 x 64 cycles
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_setprio(3);                                  // (serial code above the other signals' tiles: hscmp_mfma.h)
+    } else if constexpr (Recorr::kFused) {
+        // two workgroups per CU (b and b + #CUs share one in the first round): the second starts half a period late
+        if (P.stagger > 0 && ((b / P.cus) & 1)) {
+            const int naps = (P.stagger + 8127) / 8128;
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
 
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
@@ -825,7 +860,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                 }
                 c = wave_argmax(c);
                 if (lane == 0) sh.cred[wv] = c;
-                __syncthreads();
+                sy.full();
                 if (tid == 0) {
                     Cand<R> m = sh.cred[0];
                     for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
@@ -834,7 +869,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                     sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
                     sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
                 }
-                __syncthreads();
+                sy.full();
                 nsel = sh.nsel;
                 p_sel = sh.atom_t; k_sel = sh.atom_k; c_sel = sh.atom_c;
             }
@@ -859,24 +894,24 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                 }
                 if (lane == 0) { raw_t[j] = valid ? win.i : -1; raw_k[j] = wk; raw_c[j] = wc; }
             }
-            __syncthreads();
+            sy.full();
             if constexpr (!Recorr::kFused) HSCMP_STAMP(48);
             // :946-948 drop null coefficients (and invalid blocks): raw -> ord
             int n = block_compact(nb, [&](int i) { return raw_t[i] >= 0 && (!has_thres || fabs((double)raw_c[i]) > thres); },
-                                  raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh);
+                                  raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh, sy);
             // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
             if (n > 1) {
                 int cnt = 0;
                 for (int i = 1 + tid; i < n; i += kThreads) cnt += (ord_t[i] - ord_t[i - 1] >= W) ? 1 : 0;
-                cnt = __syncthreads_count(cnt > 0);   // > 0 iff some gap qualifies
+                cnt = sy.count(cnt > 0);   // > 0 iff some gap qualifies
                 if (cnt > 0) {
                     n = block_compact(n, [&](int i) { return i == 0 || (ord_t[i] - ord_t[i - 1] >= W); },
-                                      ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                                      ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh, sy);
                 } else {
-                    n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                    n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh, sy);
                 }
             } else {
-                n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
+                n = block_compact(n, [&](int) { return true; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh, sy);
             }
             // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals (rank sort)
             for (int i = tid; i < n; i += kThreads) {
@@ -888,7 +923,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                 }
                 ord_t[rank] = raw_t[i]; ord_k[rank] = raw_k[i]; ord_c[rank] = raw_c[i];
             }
-            __syncthreads();
+            sy.full();
             if constexpr (!Recorr::kFused) HSCMP_STAMP(49);
             // :1090-1099 weak-atom filter
             if (P.has_snr && n > 1) {
@@ -922,32 +957,32 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                                     raw_t[i] = !done ? -1 : ((double)mean >= thr) ? 1 : 0;
                                 }
                             }
-                            if (kEW < kWaves) lds_barrier();
+                            if (kEW < kWaves) sy.lds();
                         }
                     }
-                    __syncthreads();
+                    sy.full();
                     // ... and the whole workgroup streams what is left, window by window
                     for (int i = 0; i < n; ++i) {
                         if (raw_t[i] >= 0) continue;                       // uniform
                         int len, ws, we, wes;
                         len = centered_span(T, W, ord_t[i], ws, we, wes);
                         R e = (R)0, q2 = (R)0;
-                        if (len > 0 && Recorr::window_partials(P, G, A, plds, ws, we, e)) pinned_tree2(e, q2, sh.red);   // listed cells only
-                        else e = block_window_energy(P, G, sh, ord_t[i], len);
+                        if (len > 0 && Recorr::window_partials(P, G, A, plds, ws, we, e)) pinned_tree2(e, q2, sh.red, sy);   // listed cells only
+                        else e = block_window_energy(P, G, sh, ord_t[i], len, sy);
                         if (tid == 0) {
                             const R mean = e / (R)((int64_t)len * F);
                             raw_t[i] = ((double)mean >= thr) ? 1 : 0;
                         }
                     }
                 }
-                __syncthreads();
+                sy.full();
                 // keep flags live in raw_t; entry o <= i is only overwritten after flag i was read
                 // (block_compact evaluates a whole 256-chunk of predicates before it writes)
-                n = block_compact(n, [&](int i) { return raw_t[i] != 0; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh);
-                n = block_compact(n, [&](int) { return true; }, raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh);
+                n = block_compact(n, [&](int i) { return raw_t[i] != 0; }, ord_t, ord_k, ord_c, raw_t, raw_k, raw_c, sh, sy);
+                n = block_compact(n, [&](int) { return true; }, raw_t, raw_k, raw_c, ord_t, ord_k, ord_c, sh, sy);
             }
             if (tid == 0) sh.nsel = n;
-            __syncthreads();
+            sy.full();
             nsel = sh.nsel;
         }
 
@@ -968,17 +1003,17 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
         const bool hashed = sh.hashed || build_table;
         // every thread has read the event / slot counts before thread 0 advances them (the step-by-step body may
         // reach its bookkeeping without passing another barrier; the fused bodies pass several first)
-        if constexpr (!Recorr::kFused) __syncthreads();
+        if constexpr (!Recorr::kFused) sy.full();
         if (lists_full) {
-            __syncthreads();
+            sy.full();
             if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
             break;
         }
         if (build_table) {
-            __syncthreads();                         // (drains the deferred slot stores of the fused bodies)
-            slot_table_build(G, P.hmask, sh.nslots);
+            sy.full();                         // (drains the deferred slot stores of the fused bodies)
+            slot_table_build(G, P.hmask, sh.nslots, sy);
             if (tid == 0) sh.hashed = 1;
-            __syncthreads();
+            sy.full();
         }
         if constexpr (!Recorr::kFused) {
             // The pairs of one round are distinct (one per block), so the table as of the round start answers for all
@@ -988,7 +1023,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                     if (tid == 0) { unsigned pos; sh.found = slot_find(G, P.hmask, p_sel, k_sel, pos); sh.fpos = pos; }
                 } else {
                     for (int i = tid; i < nsel; i += kThreads) { unsigned pos; raw_t[i] = slot_find(G, P.hmask, ord_t[i], ord_k[i], pos); }
-                    __syncthreads();
+                    sy.full();
                 }
             }
         }
@@ -1001,7 +1036,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             if constexpr (Recorr::kFused) {
                 // policy-owned atom body: one batch of global loads, LDS-only barriers (hscmp_mfma.h);
                 // in blocked mode (k, c) were resolved at selection time
-                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0)) { fused_stop = true; break; }
+                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0, sy)) { fused_stop = true; break; }
                 continue;
             }
 
@@ -1011,11 +1046,11 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             const bool maybe_dup = !hashed && ((sh.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;    // uniform (LDS, ordered by the barriers below)
             if (maybe_dup) {
                 if (tid == 0) sh.found = -1;
-                __syncthreads();
+                sy.full();
                 const int nslots = sh.nslots;
                 for (int i = tid; i < nslots; i += kThreads)
                     if (G.slot_t[i] == p && G.slot_k[i] == k) sh.found = i;          // at most one match
-                __syncthreads();
+                sy.full();
             }
             bool new_slot = false;                   // thread 0 only
             if (tid == 0) {
@@ -1041,7 +1076,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             }
             // LDS-only barrier: nobody waits for thread 0's list stores here (the duplicate search that reads the
             // slot list comes after later full barriers), only for the control block
-            lds_barrier();
+            sy.lds();
             // the filter is updated only now: every thread has read this atom's bit (maybe_dup) before the barrier
             // above, and the next read comes after the barriers of the residual update
             if (new_slot && !hashed) sh.bloom[hb >> 5] |= 1u << (hb & 31);
@@ -1086,14 +1121,14 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                     }
                 }
             }
-            pinned_tree2(pb, pa, sh.red);
+            pinned_tree2(pb, pa, sh.red, sy);
             if (tid == 0) {
                 const R loss = pb - pa;              // :1005
                 sh.e_res = sh.e_res - loss;          // :1014
             }
             // residual writes visible to the whole workgroup -- unless the policy re-correlates from its own LDS copy of
             // the window and nothing else reads the residual before the atom's last barrier
-            if (!P.has_scale && Recorr::residual_copy_in_lds(A, plds)) lds_barrier(); else __syncthreads();
+            if (!P.has_scale && Recorr::residual_copy_in_lds(A, plds)) sy.lds(); else sy.full();
             if (P.has_scale) {
                 const int sg0 = s >> P.seg_shift, sg1 = (e - 1) >> P.seg_shift;
                 for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
@@ -1107,7 +1142,7 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             int rows_t0 = 0, rows_n = 0;
             bool rows_lds = false;
             if constexpr (!Recorr::kFused && !Recorr::kScoreOnly) rows_lds = Recorr::row_results(P, A, plds, p, rows_k, rows_c, rows_0, rows_t0, rows_n);
-            if (!rows_lds) __syncthreads();
+            if (!rows_lds) sy.full();
             if constexpr (!Recorr::kFused) HSCMP_STAMP(35);
 
             // ---- refresh the maxima of the touched segments
@@ -1136,8 +1171,8 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
                     if ((double)q >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
                 }
             }
-            __syncthreads();
-            if constexpr (!Recorr::kFused) { HSCMP_STAMP(36); if (blockIdx.x == 0 && tid == 0) HSCMP_COUNT(46); }
+            sy.full();
+            if constexpr (!Recorr::kFused) { HSCMP_STAMP(36); if (b == 0 && tid == 0) HSCMP_COUNT(46); }
             if (sh.converged) break;
         }
 
@@ -1183,9 +1218,9 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             R m = (R)0;
             for (int i = tid; i < P.nseg; i += kThreads) { const R a = sh.rseg[i]; m = a > m ? a : m; }
             m = wave_max(m);
-            __syncthreads();
+            sy.full();
             if (lane == 0) sh.red[wv] = m;
-            __syncthreads();
+            sy.full();
             if (tid == 0) {
                 for (int q = 1; q < kWaves; ++q) m = sh.red[q] > m ? sh.red[q] : m;
                 if ((double)m <= P.tol_scale) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_SCALE; }
@@ -1196,15 +1231,15 @@ __global__ __launch_bounds__(kThreads, Recorr::kMinWavesPerSimd) void iterate_ke
             sh.rounds += 1;
             sh.offset = !sh.offset;
         }
-        __syncthreads();
+        sy.full();
         if (sh.converged) break;
     }
 
-    __syncthreads();
+    sy.full();
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) g_blk[3 * b + 1] = wall_clock64();
 #endif
-    Recorr::epilogue(P, S, A, plds);
+    Recorr::epilogue(P, S, A, plds, b);
     if (tid == 0) {
         stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;
         stats[ST_ITERS] = sh.iters; stats[ST_EVENTS] = sh.nev; stats[ST_SLOTS] = sh.nslots; stats[ST_OFFSET] = sh.offset;

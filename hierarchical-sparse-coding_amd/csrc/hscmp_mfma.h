@@ -25,8 +25,10 @@
 
 #include "hscmp_kernels.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace hscmp {
@@ -207,25 +209,99 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
     return fmaxf(bs, swap_halves_f(bs, h));
 }
 
-__device__ __forceinline__ void lds_copy16(void* dst, const void* __restrict__ src, int nbytes)
+// The same tile for a kernel that runs FOUR waves per SIMD (128 VGPRs per lane; MfmaRecorr with four signals per
+// workgroup): neither the 32 B operands nor a group's 32 A operands stay in registers -- both are read from LDS one
+// chunk (4 k-steps) ahead of the MFMAs that use them, which costs LDS issue slots but no matrix-pipe time, and the
+// other three waves of the SIMD cover the latency.  Two accumulators alternate, so the 8 v_max3 of group g-1 sit
+// between the MFMAs of group g.  Same products, same order: bit-identical to mfma_tile_score.
+template <int S4C, bool HAS_W>
+__device__ __forceinline__ float mfma_tile_score_lean(const float* __restrict__ dimg, const float* __restrict__ win,
+                                                      const float* __restrict__ wts, int G, int lane)
+{
+    static_assert(S4C > 0, "compile-time chunk count only");
+    const int j = lane & 31, h = lane >> 5;
+    const float* wb = win + j + h;
+    const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
+    float bs = 0.0f;
+    auto katom = [&](int kbase, int r) { return kbase + (r & 3) + 8 * (r >> 2); };
+    const int kb0 = 4 * h;
+    // MFMA chain of group g into `acc`; with REDUCE the 8 reduction steps of the previous group's finished
+    // accumulator `accp` sit between the MFMAs (first MFMA of a chain: C = 0)
+    auto chain = [&](int g, f32x16& acc, const f32x16& accp, auto reduce_tag) {
+        constexpr bool REDUCE = decltype(reduce_tag)::value;
+        f32x4 a = dv[(g * S4C) * 64];
+#pragma unroll
+        for (int s4 = 0; s4 < S4C; ++s4) {
+            f32x4 an = a;
+            if (s4 + 1 < S4C) an = dv[(g * S4C + s4 + 1) * 64];     // the next chunk's A operands, in flight under this chunk's MFMAs
+            const float b0 = wb[8 * s4 + 0], b1 = wb[8 * s4 + 2], b2 = wb[8 * s4 + 4], b3 = wb[8 * s4 + 6];
+            if (s4 == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0, zero, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1, acc, 0, 0, 0);
+            if constexpr (REDUCE) {
+#pragma unroll
+                for (int e = (s4 * 8) / S4C; e < ((s4 + 1) * 8) / S4C; ++e)
+                    mfma_reduce_pair<HAS_W>(accp[2 * e], accp[2 * e + 1], katom(32 * (g - 1) + kb0, 2 * e), katom(32 * (g - 1) + kb0, 2 * e + 1), wts, bs);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
+            a = an;
+        }
+    };
+    auto reduce_all = [&](const f32x16& acc, int g) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(32 * g + kb0, 2 * e), katom(32 * g + kb0, 2 * e + 1), wts, bs);
+    };
+    f32x16 acc0, acc1;
+    chain(0, acc0, acc0, std::false_type());
+    int g = 1;
+#pragma unroll 1
+    for (; g + 1 < G; g += 2) {
+        chain(g, acc1, acc0, std::true_type());
+        chain(g + 1, acc0, acc1, std::true_type());
+    }
+    if (g < G) {
+        chain(g, acc1, acc0, std::true_type());
+        reduce_all(acc1, g);
+    } else {
+        reduce_all(acc0, G - 1);
+    }
+    return fmaxf(bs, swap_halves_f(bs, h));
+}
+
+__device__ __forceinline__ void lds_copy16(void* dst, const void* __restrict__ src, int nbytes, int tid = (int)threadIdx.x, int nthreads = kThreads)
 {
     // nbytes is a multiple of 16; coalesced copy, 8 loads in flight per thread before the stores
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
     const int n4 = nbytes / 16;
-    for (int base = 0; base < n4; base += 8 * kThreads) {
+    for (int base = 0; base < n4; base += 8 * nthreads) {
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = base + u * kThreads + threadIdx.x;
+            const int i = base + u * nthreads + tid;
             if (i < n4) v[u] = s4[i];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = base + u * kThreads + threadIdx.x;
+            const int i = base + u * nthreads + tid;
             if (i < n4) d4[i] = v[u];
         }
     }
+}
+
+// base of the kernel's dynamic LDS array (policies whose signals share a region in front of their own)
+__device__ __forceinline__ char* dyn_lds()
+{
+    extern __shared__ __attribute__((aligned(16))) char hscmp_dyn_lds_[];
+    return hscmp_dyn_lds_;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,6 +588,9 @@ struct TileF32 {
     template <int S4C, bool HAS_W>
     static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
     { return mfma_tile_score<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    template <int S4C, bool HAS_W>
+    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int, int lane)
+    { return mfma_tile_score_lean<S4C, HAS_W>(dimg, win, wts, G, lane); }
     template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
     { return resolve_chain<S4C>(dimg, rwin, k, S4); }
     static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index(k, w, S4); }
@@ -526,6 +605,9 @@ struct TileF64 {
     template <int S4C, bool HAS_W>
     static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
     { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    template <int S4C, bool HAS_W>
+    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
+    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }      // (no four-signal form for float64)
     template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
     { return resolve_chain_f64<S4C>(dimg, rwin, k, S4); }
     static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index_f64(k, w, S4); }
@@ -542,10 +624,16 @@ template <typename R> inline bool mfma_supported(int K, int W, int F)
     return bytes <= Tile::kMaxImageBytes && W <= 128;
 }
 
-template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
+// GS = signals per workgroup.  1: the signal owns a 256-thread workgroup (two per CU: each holds its own 64 KB image).
+// 4: four signals share a 1024-thread workgroup and ONE image (float32 only): four waves per SIMD, each from a
+// different signal, so that while one signal is in its serial phases (loads, resolve, residual update, maxima, stop
+// rules) the matrix pipe has three other signals' tiles to run.  The waves of a signal meet at SoftSync barriers.
+template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
-    static constexpr int kMinWavesPerSimd = 1;
+    static constexpr int kGroup = GS;
+    static constexpr int kMinWavesPerSimd = GS;         // (launch bounds: 4 signals x 4 waves = 4 waves per SIMD)
+    using Sync = typename std::conditional<GS == 1, HwSync, SoftSync>::type;
     static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = true;    // best_c[t] holds max_k |c[t,k]*w_k|; (k, c) resolved on selection
     static constexpr int kBook = 192;           // bookkeeping thread: lane 0 of wave 3, idle while waves 0.. rescan segments
@@ -561,6 +649,11 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     static __device__ __forceinline__ bool residual_copy_in_lds(const MfmaArgsT<R>&, char*) { return false; }
     using Shared = IterSharedT<R, kMfmaMaxSeg, false, false>;
     using Args = MfmaArgsT<R>;
+    static __device__ __forceinline__ Sync make_sync(Shared& sh)
+    {
+        if constexpr (GS == 1) return HwSync();
+        else { SoftSync sy; sy.bar = &sh.bar; sy.cnt = &sh.bar_cnt; sy.target = 0u; return sy; }
+    }
 
     struct Layout {
         R* dimg; R* wts; R* win; R* esq; R* sbs; unsigned* bloom;
@@ -570,22 +663,42 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
 
     static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + TP - 1) / TP) * TP + 8 * S4 + 32; }
     static __host__ __device__ int segbuf_len(int W, int seg) { return ((2 * W - 2) / seg + 2) * seg; }
-    static size_t extra_lds_bytes(const DevParams& P, const Args& A)
+    // LDS: what the signals of a workgroup share (dictionary image, weights), then per signal the control block and
+    // its windows.  GS == 1: [control][image | weights | windows ...] as one region behind the control block.
+    static __host__ __device__ size_t shared_lds_bytes(const Args& A)
     {
-        const size_t relems = (size_t)A.G * A.S4 * Tile::kChunkElems + (HAS_W ? Tile::GA * A.G : 0) + window_floats(P.W, A.S4) +
-                              2 * 8 * A.S4 + (size_t)segbuf_len(P.W, P.seg) + 8 * A.S4 + kWaves * 8 * A.S4;
+        return ((size_t)A.G * A.S4 * Tile::kChunkElems + (HAS_W ? Tile::GA * A.G : 0)) * sizeof(R);      // (a multiple of 16)
+    }
+    static __host__ __device__ size_t private_lds_bytes(const DevParams& P, const Args& A)
+    {
+        const size_t relems = (size_t)window_floats(P.W, A.S4) + 2 * 8 * A.S4 + (size_t)segbuf_len(P.W, P.seg) + 8 * A.S4 + kWaves * 8 * A.S4;
         return relems * sizeof(R) + kBloomWords * sizeof(unsigned) + kEdgeWords * sizeof(unsigned long long);
+    }
+    static __host__ __device__ size_t per_signal_lds_bytes(const DevParams& P, const Args& A)
+    {
+        return ((sizeof(Shared) + 15) / 16) * 16 + ((private_lds_bytes(P, A) + 15) / 16) * 16;
+    }
+    static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return shared_lds_bytes(A) + private_lds_bytes(P, A); }   // GS == 1
+    static size_t total_lds_bytes(const DevParams& P, const Args& A)
+    {
+        if (GS == 1) return ((sizeof(Shared) + 15) / 16) * 16 + extra_lds_bytes(P, A);
+        return shared_lds_bytes(A) + (size_t)GS * per_signal_lds_bytes(P, A);
+    }
+    static __device__ __forceinline__ int signal_lds_offset(const DevParams& P, const Args& A)
+    {
+        if constexpr (GS == 1) return 0;
+        else return (int)(shared_lds_bytes(A) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) * per_signal_lds_bytes(P, A));
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
         const int S4 = S4C > 0 ? S4C : A.S4;
         Layout L;
-        L.dimg = reinterpret_cast<R*>(lds);
+        L.dimg = reinterpret_cast<R*>(GS == 1 ? lds : dyn_lds());
         L.wts = L.dimg + A.G * S4 * Tile::kChunkElems;
         L.nwin = window_floats(P.W, S4);
         L.wp = 8 * S4;
         L.nsbmax = segbuf_len(P.W, P.seg);
-        L.win = L.wts + (HAS_W ? Tile::GA * A.G : 0);
+        L.win = GS == 1 ? L.wts + (HAS_W ? Tile::GA * A.G : 0) : reinterpret_cast<R*>(lds);
         L.esq = L.win + L.nwin;
         L.sbs = L.esq + 2 * L.wp;
         L.bloom = reinterpret_cast<unsigned*>(L.sbs + L.nsbmax);
@@ -595,33 +708,53 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         return L;
     }
 
-    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds)
+    // what the signals of a workgroup share: image and weights by all its threads, the barrier counters, then the
+    // ONE hardware barrier of the kernel (every wave is still here: nobody has returned yet)
+    static __device__ __forceinline__ void prologue_shared(const DevParams& P, const State<R>& S, const Args& A, char* smem)
+    {
+        if constexpr (GS > 1) {
+            const int S4 = S4C > 0 ? S4C : A.S4;
+            R* dimg = reinterpret_cast<R*>(smem);
+            R* wts = dimg + A.G * S4 * Tile::kChunkElems;
+            lds_copy16(dimg, A.dimg, A.G * S4 * Tile::kChunkElems * (int)sizeof(R), (int)threadIdx.x, GS * kThreads);
+            if (HAS_W) for (int i = threadIdx.x; i < Tile::GA * A.G; i += GS * kThreads) wts[i] = i < P.K ? S.weights[i] : (R)0;
+            if (ltid() == 0) {
+                Shared* sh = reinterpret_cast<Shared*>(smem + signal_lds_offset(P, A));
+                sh->bar = 0u; sh->bar_cnt = 0;
+            }
+            __syncthreads();
+        }
+    }
+
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds, int b, Sync& sy)
     {
         const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
-        const int b = blockIdx.x;
-        lds_copy16(L.dimg, A.dimg, A.G * S4 * Tile::kChunkElems * (int)sizeof(R));
-        if (HAS_W) for (int i = threadIdx.x; i < Tile::GA * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : (R)0;
-        for (int i = threadIdx.x; i < L.nwin; i += kThreads) L.win[i] = (R)0;   // the tail behind the span stays zero
-        for (int i = threadIdx.x; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
-        for (int i = threadIdx.x; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = (R)0;   // padded taps stay zero
-        if (threadIdx.x < kEdgeWords) L.edge[threadIdx.x] = S.edge[kEdgeWords * b + threadIdx.x];
-        __syncthreads();
+        const int tid = ltid();
+        if constexpr (GS == 1) {
+            lds_copy16(L.dimg, A.dimg, A.G * S4 * Tile::kChunkElems * (int)sizeof(R));
+            if (HAS_W) for (int i = tid; i < Tile::GA * A.G; i += kThreads) L.wts[i] = i < P.K ? S.weights[i] : (R)0;
+        }
+        for (int i = tid; i < L.nwin; i += kThreads) L.win[i] = (R)0;   // the tail behind the span stays zero
+        for (int i = tid; i < kBloomWords; i += kThreads) L.bloom[i] = 0u;
+        for (int i = tid; i < (1 + kWaves) * L.wp; i += kThreads) L.rwin[i] = (R)0;   // padded taps stay zero
+        if (tid < kEdgeWords) L.edge[tid] = S.edge[kEdgeWords * b + tid];
+        sy.full();
         // resumed launch: re-enter the (t,k) pairs selected so far
         const int nslots = S.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
         const int* st = S.slot_t + (int64_t)b * P.cap;
         const int* sk = S.slot_k + (int64_t)b * P.cap;
-        for (int i = threadIdx.x; i < nslots; i += kThreads) {
+        for (int i = tid; i < nslots; i += kThreads) {
             const unsigned h = bloom_hash(st[i], sk[i]);
             atomicOr(&L.bloom[h >> 5], 1u << (h & 31));
         }
-        // visibility: the caller's next __syncthreads()
+        // visibility: the caller's next barrier
     }
 
-    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>& S, const Args& A, char* lds)
+    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>& S, const Args& A, char* lds, int b)
     {
         const Layout L = layout(P, A, lds);
-        if (threadIdx.x < kEdgeWords) S.edge[kEdgeWords * blockIdx.x + threadIdx.x] = L.edge[threadIdx.x];
+        if (ltid() < kEdgeWords) S.edge[kEdgeWords * b + ltid()] = L.edge[ltid()];
     }
 
     // never reached: iterate_kernel hands the whole atom body to apply_atom() when kFused
@@ -635,7 +768,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     {
         const Layout L = layout(P, A, lds);
         const int S4 = S4C > 0 ? S4C : A.S4;
-        R* rw = L.rwin_w + (threadIdx.x >> 6) * L.wp;
+        R* rw = L.rwin_w + (ltid() >> 6) * L.wp;
         __builtin_amdgcn_wave_barrier();
         for (int w = lane; w < P.W; w += 64) rw[w] = edge_window_value(Gs.r, P.T, t - P.off + w, t, L.edge);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -660,15 +793,15 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
     // Returns true when the atom loop must stop.
     template <typename SH>
     static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<R>& S, const Sig<R>& Gs,
-                                                      SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved)
+                                                      SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved, Sync& sy)
     {
         (void)S;
-        const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = tid >> 6;
         const int S4 = S4C > 0 ? S4C : A.S4;
         const Layout L = layout(P, A, lds);
         if (sh.nev >= P.cap) {                                  // event list full (uniform: LDS value)
             if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
-            __syncthreads();
+            sy.full();
             return true;
         }
         HSCMP_STAMP_BEGIN();
@@ -717,7 +850,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
 
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {
-            lds_barrier();                                      // Bx: the position's window is in LDS
+            sy.lds();                                      // Bx: the position's window is in LDS
             Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
             R bc = (R)0;
             for (int kk = tid; kk < P.K; kk += kThreads) {
@@ -729,7 +862,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             const Cand<R> wbest = wave_argmax(best);
             if (best.i == wbest.i && wbest.i != INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = bc; }   // the owner lane
             if (lane == 0 && wbest.i == INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = (R)0; }
-            lds_barrier();                                      // By
+            sy.lds();                                      // By
             Cand<R> m = sh.cred[0];
             c = sh.red[0];
 #pragma unroll
@@ -738,7 +871,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
                 // (with a residual-scale rule the reference tests that rule first, :1145-1153: the slow rules name the reason)
                 if (tid == 0) { sh.converged = 1; sh.nullsel = 1; if (!P.has_scale && sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
-                __syncthreads();
+                sy.full();
                 return true;
             }
         }
@@ -752,7 +885,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         unsigned long long probe_key = kSlotEmpty;
         unsigned probe_pos = 0;
         if (maybe_dup) {
-            __syncthreads();                                    // drains the bookkeeper's deferred slot stores
+            sy.full();                                    // drains the bookkeeper's deferred slot stores
             const int nslots = sh.nslots;
             for (int i = tid; i < nslots; i += kThreads)
                 if (Gs.slot_t[i] == p && Gs.slot_k[i] == k) sh.found = i;      // at most one match
@@ -791,10 +924,10 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         }
         HSCMP_STAMP(0);                                         // phase A + resolve + update, up to B1
         if (P.has_scale) {                                      // toleranceResidualScale: max|r| of touched segments
-            __syncthreads();                                    // B1 (+ residual stores visible to the scan)
+            sy.full();                                    // B1 (+ residual stores visible to the scan)
             for (int sg = (s >> P.seg_shift) + wv; sg <= ((e - 1) >> P.seg_shift); sg += kWaves) rscan_segment(P, Gs, sh, sg, lane);
         } else {
-            lds_barrier();                                      // B1: window, squares, segment buffer in LDS
+            sy.lds();                                      // B1: window, squares, segment buffer in LDS
         }
         HSCMP_STAMP(1);                                         // B1
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
@@ -812,16 +945,23 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         HSCMP_STAMP(2);                                         // energy partials
 
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
+        // Four waves per SIMD: the vector instructions of a signal's serial phases must not queue behind the MFMAs of
+        // the three other signals (one issue slot per 64-cycle MFMA each, shared by age: measured 4.7x longer serial
+        // phases).  Serial code runs at priority 3 and takes every slot it can use; the tiles run at priority 0.
+        if constexpr (GS > 1) __builtin_amdgcn_s_setprio(0);
         for (int q = wv; q < ntiles; q += kWaves) {
-            const R sc = Tile::template tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
+            R sc;
+            if constexpr (GS > 1 && S4C > 0) sc = Tile::template tile_score_lean<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
+            else sc = Tile::template tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
             const int row = TP * q + lane, t = p - (W - 1) + row;
             if (lane < TP && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
                 Gs.bc[t] = sc;
                 L.sbs[t - segbase] = sc;
             }
         }
+        if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
         HSCMP_STAMP(3);                                         // MFMA tile(s) of this wave
-        lds_barrier();                                          // B4: per-row scores in the segment buffer
+        sy.lds();                                          // B4: per-row scores in the segment buffer
         HSCMP_STAMP(4);                                         // B4
 
         // ---- maxima of the touched segments, out of LDS
@@ -876,7 +1016,7 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
             }
         }
         HSCMP_STAMP(5);                                         // segment maxima + bookkeeping
-        __syncthreads();                                        // B5: also drains this atom's residual / score stores
+        sy.full();                                        // B5: also drains this atom's residual / score stores
         HSCMP_STAMP(6);                                         // B5
         if (tid == kBook) {
             // deferred global stores of the bookkeeping: nobody waits for them (the duplicate scan
@@ -890,33 +1030,39 @@ template <typename Tile, int S4C, bool HAS_W> struct MfmaRecorr {
         }
         HSCMP_STAMP(7);                                         // deferred stores
 #ifdef HSCMP_DBG_STAMPS
-        if (blockIdx.x == 0 && tid == 0) g_stamps[15] += 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[15] += 1;
 #endif
         return sh.converged != 0;
     }
 };
 
 // host-side dispatch -----------------------------------------------------------------------------
+// CUs of the current device (queried per device: a process may drive several GPUs)
+inline int mfma_device_cus()
+{
+    static int cus_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return cus_of[dev];
+}
+
 template <typename Tile, int S4C, bool HAS_W>
 static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const State<typename Tile::R>& S,
-                                   const MfmaArgsT<typename Tile::R>& A)
+                                   const MfmaArgsT<typename Tile::R>& A, bool dry = false)
 {
     using R = typename Tile::R;
     const size_t lds = ((size_t)A.G * A.S4 * Tile::kChunkElems + Tile::GA * A.G + kMfmaChunk + 8 * A.S4 + 32) * sizeof(R);
     auto kern = corr_init_mfma_kernel<Tile, S4C, HAS_W>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (dry) return 0;
     // persistent grid: as many workgroups as are resident at once (LDS-bound), capped by the work
-    static int cus = 0;          // same device family in one process: query once
-    static int per_cu = 0;       // per template instantiation
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    }
+    const int cus = mfma_device_cus();
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const int64_t nitems = (int64_t)((P.T + kMfmaChunk - 1) / kMfmaChunk) * P.B;
     int64_t grid = (int64_t)cus * per_cu;
     if (const char* e = getenv("HSCMP_INIT_PER_CU")) grid = (int64_t)cus * std::max(1, atoi(e));      // diagnostic: fewer resident workgroups
@@ -925,26 +1071,53 @@ static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const
     return 0;
 }
 
-template <typename Tile, int S4C, bool HAS_W>
-static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P0, const State<typename Tile::R>& S,
-                                 const MfmaArgsT<typename Tile::R>& A)
+// signals per workgroup of the last MFMA loop this thread launched (reported by hscmp_last_variant)
+inline int& mfma_last_group() { static thread_local int g = 1; return g; }
+
+template <typename Tile, int S4C, bool HAS_W, int GS>
+static int mfma_launch_iterate_g(hipStream_t stream, const DevParams& P0, const State<typename Tile::R>& S,
+                                 const MfmaArgsT<typename Tile::R>& A, bool dry)
 {
-    using Pol = MfmaRecorr<Tile, S4C, HAS_W>;
+    using Pol = MfmaRecorr<Tile, S4C, HAS_W, GS>;
     DevParams P = P0;
     set_segments(P, Pol::kMaxSegments);
-    size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    size_t lds = Pol::total_lds_bytes(P, A);
+    if (GS > 1 && lds > (size_t)160 * 1024) return -1;
+    // one tile = (K/32 groups) x (W/2 MFMAs) x 64 cycles = K x W cycles of the matrix pipe
+    P.stagger = (int)std::min<int64_t>((int64_t)A.G * 32 * A.S4 * 8 * 11 / 10, 1 << 20);
+    P.cus = mfma_device_cus();
+    if (GS == 1) P.stagger = 0;
+    if (const char* e = getenv("HSCMP_STAGGER")) P.stagger = atoi(e);            // diagnostic
     if (const char* pad = getenv("HSCMP_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: force a lower occupancy
     auto kern = iterate_kernel<typename Tile::R, Pol>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (dry) return 0;
     if (getenv("HSCMP_DEBUG")) {
         int per_cu = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds);
-        fprintf(stderr, "[hscmp] iterate_kernel<mfma %s S4=%d w=%d>: dynamic LDS %zu B (control %zu B), occupancy API %d blocks/CU (%s), seg=%d nseg=%d\n",
-                sizeof(typename Tile::R) == 4 ? "f32" : "f64", S4C, (int)HAS_W, lds, sizeof(typename Pol::Shared), per_cu,
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GS * kThreads, lds);
+        fprintf(stderr, "[hscmp] iterate_kernel<mfma %s S4=%d w=%d, %d signal(s) per workgroup>: dynamic LDS %zu B (control %zu B), occupancy API %d blocks/CU (%s), seg=%d nseg=%d\n",
+                sizeof(typename Tile::R) == 4 ? "f32" : "f64", S4C, (int)HAS_W, GS, lds, sizeof(typename Pol::Shared), per_cu,
                 hipGetErrorString(e), P.seg, P.nseg);
     }
-    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, stream, P, S, A);
+    hipLaunchKernelGGL(kern, dim3((P.B + GS - 1) / GS), dim3(GS * kThreads), lds, stream, P, S, A);
+    mfma_last_group() = GS;
     return 0;
+}
+
+// Four signals per workgroup pay off once a CU would otherwise hold more than two signals in turn (B > 2 x CUs):
+// one round of four overlapping signals per CU instead of two rounds of two.  HSCMP_MFMA_QUAD=0/1 forces the choice
+// (tests run both; the results are bit-identical).  Returns the signals per workgroup that `dry == false` launched.
+template <typename Tile, int S4C, bool HAS_W>
+static int mfma_launch_iterate_t(hipStream_t stream, const DevParams& P, const State<typename Tile::R>& S,
+                                 const MfmaArgsT<typename Tile::R>& A, bool dry = false)
+{
+    bool quad = false;
+    if constexpr (sizeof(typename Tile::R) == 4 && S4C > 0) {
+        quad = P.B > 2 * mfma_device_cus();
+        if (const char* e = getenv("HSCMP_MFMA_QUAD")) quad = atoi(e) != 0;
+        if (quad && mfma_launch_iterate_g<Tile, S4C, HAS_W, 4>(stream, P, S, A, dry) == 0) return 0;
+    }
+    return mfma_launch_iterate_g<Tile, S4C, HAS_W, 1>(stream, P, S, A, dry);
 }
 
 template <typename R> inline MfmaArgsT<R> mfma_args(const DevParams& P, const State<R>& S, const R* dimg)
@@ -959,21 +1132,22 @@ template <typename R> inline MfmaArgsT<R> mfma_args(const DevParams& P, const St
     do {                                                                                              \
         const bool hw = A.has_w != 0;                                                                 \
         switch (A.S4) {                                                                               \
-        case 8: return hw ? FN<Tile, 8, true>(stream, P, S, A) : FN<Tile, 8, false>(stream, P, S, A);  \
-        case 4: return hw ? FN<Tile, 4, true>(stream, P, S, A) : FN<Tile, 4, false>(stream, P, S, A);  \
-        case 2: return hw ? FN<Tile, 2, true>(stream, P, S, A) : FN<Tile, 2, false>(stream, P, S, A);  \
-        default: return hw ? FN<Tile, 0, true>(stream, P, S, A) : FN<Tile, 0, false>(stream, P, S, A); \
+        case 8: return hw ? FN<Tile, 8, true>(stream, P, S, A, dry) : FN<Tile, 8, false>(stream, P, S, A, dry);  \
+        case 4: return hw ? FN<Tile, 4, true>(stream, P, S, A, dry) : FN<Tile, 4, false>(stream, P, S, A, dry);  \
+        case 2: return hw ? FN<Tile, 2, true>(stream, P, S, A, dry) : FN<Tile, 2, false>(stream, P, S, A, dry);  \
+        default: return hw ? FN<Tile, 0, true>(stream, P, S, A, dry) : FN<Tile, 0, false>(stream, P, S, A, dry); \
         }                                                                                             \
     } while (0)
 
-template <typename R> inline int mfma_launch_corr_init(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg)
+// dry: only check that the kernel can be configured for this shape (LDS attribute), queue nothing
+template <typename R> inline int mfma_launch_corr_init(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg, bool dry = false)
 {
     using Tile = typename TileOf<R>::type;
     const MfmaArgsT<R> A = mfma_args<R>(P, S, dimg);
     HSCMP_MFMA_DISPATCH(mfma_launch_corr_init_t);
 }
 
-template <typename R> inline int mfma_launch_iterate(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg)
+template <typename R> inline int mfma_launch_iterate(hipStream_t stream, const DevParams& P, const State<R>& S, const R* dimg, bool dry = false)
 {
     using Tile = typename TileOf<R>::type;
     const MfmaArgsT<R> A = mfma_args<R>(P, S, dimg);

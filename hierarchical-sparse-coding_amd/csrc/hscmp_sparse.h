@@ -625,6 +625,11 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     static constexpr bool kScoreOnly = false;
     using Shared = IterSharedT<R, kMaxSegments, false>;
     using Args = SparseArgs<R>;
+    static constexpr int kGroup = 1;                    // one signal per workgroup: the hardware barrier
+    using Sync = HwSync;
+    static __device__ __forceinline__ Sync make_sync(Shared&) { return Sync(); }
+    static __device__ __forceinline__ void prologue_shared(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __device__ __forceinline__ int signal_lds_offset(const DevParams&, const Args&) { return 0; }
     static __host__ __device__ bool has_bits(const DevParams& P, const Args& A) { return A.rl_cnt == nullptr && A.rowflag != nullptr && P.T <= kRowBitsMaxT; }
     // policy LDS: SparseLds | staged dictionary lists + weights (when small) | row bitmap (when T allows)
     static __host__ __device__ size_t bits_offset(const DevParams& P, const Args& A) { return sparse_lds_bytes<R>(A.caps) + staged_dict_bytes(P, A); }
@@ -638,7 +643,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
         return dict_view(P, A, lds + sparse_lds_bytes<R>(A.caps)).wts;
     }
     // the row-occupancy bitmap of this signal: flags written by the initial correlation (or an earlier launch)
-    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>&, const Args& A, char* lds)
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>&, const Args& A, char* lds, int, Sync&)
     {
         stage_dict(P, A, lds + sparse_lds_bytes<R>(A.caps));
         if (!has_bits(P, A)) { __syncthreads(); return; }                  // (row lists need no per-launch state)
@@ -653,7 +658,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
         }
         __syncthreads();
     }
-    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>&, const Args& A, char* lds)
+    static __device__ __forceinline__ void epilogue(const DevParams& P, const State<R>&, const Args& A, char* lds, int)
     {
         if (!has_bits(P, A)) return;                        // (the caller's barrier made all bits visible)
         const unsigned* bits = bits_of(P, A, lds);

@@ -53,12 +53,19 @@ def _worker(rank, world, port, out_dir):
         first, last = shard_bounds(7, world, rank)
         # every rank generates ITS OWN shard from the per-signal streams
         shard = synth.make_batch(D, 512, first, last - first, kind='planted', nb_atoms=12, seed=5)
-        out = encode_sharded(shard, D, encode_fn=_oracle_encode, nbNonzeroCoefs=12)
+        out = encode_sharded(shard, D, encode_fn=_oracle_encode, residuals=True, nbNonzeroCoefs=12)
+        lean = encode_sharded(shard, D, encode_fn=_oracle_encode, nbNonzeroCoefs=12)       # default: per-signal results only
+        assert lean['residuals'] is None and lean['bytes_per_signal'] == out['bytes_per_signal']
         if rank == 0:
+            import golden_util as gu
+            trip = [gu.csc_triplets(c) for c in out['coefficients']]
             np.savez(os.path.join(out_dir, 'gathered.npz'),
                      t=np.concatenate([e[0] for e in out['events']]), k=np.concatenate([e[1] for e in out['events']]),
                      c=np.concatenate([e[2] for e in out['events']]), n=np.array([len(e[0]) for e in out['events']]),
-                     residuals=out['residuals'], stats=out['stats'])
+                     residuals=out['residuals'], stats=out['stats'], energies=out['energies'],
+                     bytes_per_signal=out['bytes_per_signal'],
+                     coef_row=np.concatenate([a[0] for a in trip]), coef_col=np.concatenate([a[1] for a in trip]),
+                     coef_data=np.concatenate([a[2] for a in trip]))
     finally:
         dist.destroy_process_group()
 
@@ -79,4 +86,40 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert np.array_equal(got['k'], np.concatenate([e[1] for e in ref.events]))
     assert np.array_equal(got['c'], np.concatenate([e[2] for e in ref.events]))
     assert np.array_equal(got['residuals'], ref.residuals)
-    assert got['stats'].shape == (7, 8)
+    assert got['stats'].shape == (7, 8) and np.array_equal(got['stats'][:, :5], ref.stats[:, :5])
+    assert np.array_equal(got['energies'], ref.energies)
+    # the payload of the collectives is the per-signal results only: a few KB per signal (north_star)
+    assert 0 < int(got['bytes_per_signal']) <= 4096
+    # the coefficient matrices rebuilt from the gathered events equal the encoder's own
+    import golden_util as gu
+    trip = [gu.csc_triplets(c) for c in ref.coefficients]
+    assert np.array_equal(got['coef_row'], np.concatenate([a[0] for a in trip]))
+    assert np.array_equal(got['coef_col'], np.concatenate([a[1] for a in trip]))
+    assert np.array_equal(got['coef_data'], np.concatenate([a[2] for a in trip]))
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from hsc_amd.parallel import broadcast_dictionary
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(3)
+        D = rs.standard_normal((6, 5, 3)) if rank == 0 else None            # float64, 3-D, with weights
+        w = rs.uniform(0.5, 1.0, size=6) if rank == 0 else None
+        D2, w2 = broadcast_dictionary(D, w, src=0)
+        np.savez(os.path.join(out_dir, 'bcast%d.npz' % rank), D=D2, w=w2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dictionary_broadcast_is_a_tensor_broadcast(tmp_path):
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(os.path.join(str(tmp_path), 'bcast%d.npz' % r)) for r in (0, 1))
+    assert a['D'].dtype == np.float64 and a['D'].shape == (6, 5, 3)
+    assert np.array_equal(a['D'], b['D']) and np.array_equal(a['w'], b['w'])
