@@ -22,7 +22,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
-           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_encode_batch',
+           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_hierarchy_epilogue', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
@@ -48,8 +48,19 @@ class HscmpDeviceView(ctypes.Structure):
                 ('best_c', ctypes.c_void_p), ('best_k', ctypes.c_void_p)]
 
 
+class HscmpEpilogueLevel(ctypes.Structure):
+    _fields_ = [('col0', ctypes.c_int32), ('col1', ctypes.c_int32), ('scale', ctypes.c_int32), ('rep_is_f32', ctypes.c_int32),
+                ('rep', ctypes.c_void_p)]
+
+
+EVENT_DTYPE = np.dtype('int32,int32,int32,float32')      # hsc/dataset.py:752 (time, level, index, coefficient)
+
+
 class HscmpError(RuntimeError):
-    pass
+    code = 0            # hscmp_status of the failed call (include/hscmp.h), 0 when raised by the Python layer
+
+
+ERR_ALLOC = -6
 
 
 _lib = None
@@ -81,6 +92,7 @@ def load_library():
     lib.hscmp_assign_windows.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.hscmp_host_slots_to_csc.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_double, vp, vp, vp]
     lib.hscmp_host_overlap_add.argtypes = [vp, ctypes.c_int64, ci, vp, vp, vp, ctypes.c_int64, vp, ci, ci]
+    lib.hscmp_hierarchy_epilogue.argtypes = [vp, vp, ci, ctypes.POINTER(HscmpEpilogueLevel), ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
@@ -175,7 +187,9 @@ class Engine(object):
 
     def _check(self, rc, what):
         if rc != 0:
-            raise HscmpError('%s failed (%d): %s' % (what, rc, self._lib.hscmp_last_error(self._h).decode()))
+            ex = HscmpError('%s failed (%d): %s' % (what, rc, self._lib.hscmp_last_error(self._h).decode()))
+            ex.code = int(rc)
+            raise ex
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.hscmp_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), 'hscmp_set_stream')
@@ -265,6 +279,40 @@ class Engine(object):
         self._check(self._lib.hscmp_encode_batch_from_level(self._h, prev._h, int(first), int(count), ctypes.c_double(minc),
                                                             ctypes.byref(params)), 'hscmp_encode_batch_from_level')
         self._batch = (int(count), prev._batch[1], int(params.max_events))
+
+    def hierarchy_epilogue(self, level0, first, levels, minCoefficients, slot_counts, want_events=True, want_residual=True):
+        """hscmp_hierarchy_epilogue on this (last-level) engine.  levels: list of (col0, col1, representations [K,scale(,Fd)]).
+        slot_counts: int array [count], the slot count of every signal (stats[:, STAT_SLOTS]).
+        Returns (n [count], colptr [count, K+1], offsets [count+1], indices, data, events or None, residual or None)."""
+        count, T, _ = self._batch
+        Fd = level0.F
+        arr = (HscmpEpilogueLevel * len(levels))()
+        keep = []
+        for i, (c0, c1, rep) in enumerate(levels):
+            arr[i].col0, arr[i].col1 = int(c0), int(c1)
+            if rep is None or c1 <= c0:
+                arr[i].scale, arr[i].rep_is_f32, arr[i].rep = 0, 1, None
+                continue
+            r = np.ascontiguousarray(rep.reshape((rep.shape[0], rep.shape[1], -1)))
+            if r.dtype not in (np.float32, np.float64):
+                r = r.astype(np.float64)
+            assert r.shape[0] >= c1 and r.shape[2] == Fd
+            keep.append(r)
+            arr[i].scale, arr[i].rep_is_f32, arr[i].rep = int(r.shape[1]), 1 if r.dtype == np.float32 else 0, r.ctypes.data
+        offsets = np.zeros(count + 1, dtype=np.int64)
+        np.cumsum(np.asarray(slot_counts, dtype=np.int64), out=offsets[1:])
+        total = int(offsets[-1])
+        n = np.empty(count, dtype=np.int32)
+        colptr = np.empty((count, self.K + 1), dtype=np.int32)
+        indices = np.empty(max(total, 1), dtype=np.int32)
+        data = np.empty(max(total, 1), dtype=np.float64)
+        events = np.empty(max(total, 1), dtype=EVENT_DTYPE) if want_events else None
+        residual = np.empty((count, T, Fd), dtype=np.float64) if want_residual else None
+        minc = float('nan') if minCoefficients is None else float(minCoefficients)
+        self._check(self._lib.hscmp_hierarchy_epilogue(self._h, level0._h, int(first), arr, len(levels), ctypes.c_double(minc), _ptr(offsets),
+                                                       _ptr(n), _ptr(colptr), _ptr(indices), _ptr(data), _ptr(events), _ptr(residual)),
+                    'hscmp_hierarchy_epilogue')
+        return n, colptr, offsets, indices, data, events, residual
 
     def continue_rounds(self, max_rounds):
         self._check(self._lib.hscmp_continue(self._h, int(max_rounds)), 'hscmp_continue')

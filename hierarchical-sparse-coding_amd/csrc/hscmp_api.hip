@@ -9,6 +9,7 @@
 #include "hscmp_kernels.h"
 #include "hscmp_mfma.h"
 #include "hscmp_sparse.h"
+#include "hscmp_epilogue.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -66,6 +67,10 @@ struct hscmp_ctx {
     bool timed = false;
     bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
     bool mfma_state = false;        // the batch's table-free state is the score-only form of the MFMA kernels
+    const void* last_x_dev = nullptr;   // device address of the signals of the last encode (hscmp_hierarchy_epilogue reads them)
+    // epilogue workspace (grow-only)
+    void* d_epi[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_epi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static thread_local std::string g_err;
@@ -121,6 +126,7 @@ extern "C" int hscmp_create(hscmp_ctx** out, int device_id)
 
 static void free_all(hscmp_ctx* c)
 {
+    for (void* p : c->d_epi) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_Dc, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
                     c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_hkey, c->d_hval, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -551,6 +557,7 @@ static int encode_common(hscmp_ctx* ctx, const void* x, bool host, int B, int T,
         xd = ctx->d_x;
     }
     ctx->P = P; ctx->last = *params; ctx->B = B; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
+    ctx->last_x_dev = xd;
     rc = ctx->dtype == HSCMP_F32 ? run_encode<float>(ctx, P, xd) : run_encode<double>(ctx, P, xd);
     if (rc) return rc;
     ctx->have_batch = true;
@@ -652,34 +659,42 @@ extern "C" int hscmp_grow_events(hscmp_ctx* ctx, int new_max_events)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t es = esize(ctx->dtype), B = (size_t)ctx->B, oc = (size_t)ctx->cap, nc = (size_t)new_max_events;
-    struct Row { void** p; size_t* cap; size_t elem; };
-    Row rows[] = {{(void**)&ctx->d_ev_t, &ctx->caps[4], 4}, {(void**)&ctx->d_ev_k, &ctx->caps[5], 4}, {(void**)&ctx->d_ev_c, &ctx->caps[6], es},
-                  {(void**)&ctx->d_slot_t, &ctx->caps[7], 4}, {(void**)&ctx->d_slot_k, &ctx->caps[8], 4}, {(void**)&ctx->d_slot_a, &ctx->caps[9], 8}};
-    for (const Row& r : rows) {
-        void* fresh = nullptr;
-        hipError_t e = hipMalloc(&fresh, B * nc * r.elem);
-        if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", B * nc * r.elem, hipGetErrorString(e));
-        HIP_TRY(ctx, hipMemcpy2D(fresh, nc * r.elem, *r.p, oc * r.elem, oc * r.elem, B, hipMemcpyDeviceToDevice));
-        (void)hipFree(*r.p);
-        *r.p = fresh; *r.cap = B * nc * r.elem;
-    }
-    std::vector<int> stats(B * ST_COUNT);
-    HIP_TRY(ctx, hipMemcpy(stats.data(), ctx->d_stats, stats.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < B; ++b)
-        if (stats[b * ST_COUNT + ST_STOP] == STOP_CAPACITY) stats[b * ST_COUNT + ST_STOP] = STOP_RUNNING;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_stats, stats.data(), stats.size() * sizeof(int), hipMemcpyHostToDevice));
+    struct Row { void** p; size_t* cap; size_t elem; void* fresh; };
+    Row rows[] = {{(void**)&ctx->d_ev_t, &ctx->caps[4], 4, nullptr}, {(void**)&ctx->d_ev_k, &ctx->caps[5], 4, nullptr}, {(void**)&ctx->d_ev_c, &ctx->caps[6], es, nullptr},
+                  {(void**)&ctx->d_slot_t, &ctx->caps[7], 4, nullptr}, {(void**)&ctx->d_slot_k, &ctx->caps[8], 4, nullptr}, {(void**)&ctx->d_slot_a, &ctx->caps[9], 8, nullptr}};
     // the slot hash table follows the capacity; the loop rebuilds its contents from the slot list on the next launch
     const unsigned hmask = slot_hash_mask(new_max_events);
-    struct Tab { void** p; size_t* cap; size_t elem; };
-    Tab tabs[] = {{(void**)&ctx->d_hkey, &ctx->cap_hkey, sizeof(unsigned long long)}, {(void**)&ctx->d_hval, &ctx->cap_hval, sizeof(int)}};
-    for (const Tab& t : tabs) {
-        const size_t bytes = B * ((size_t)hmask + 1) * t.elem;
-        if (*t.p && *t.cap >= bytes) continue;
-        if (*t.p) { (void)hipFree(*t.p); *t.p = nullptr; *t.cap = 0; }
-        hipError_t e = hipMalloc(t.p, bytes);
-        if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        *t.cap = bytes;
+    struct Tab { void** p; size_t* cap; size_t elem; void* fresh; };
+    Tab tabs[] = {{(void**)&ctx->d_hkey, &ctx->cap_hkey, sizeof(unsigned long long), nullptr}, {(void**)&ctx->d_hval, &ctx->cap_hval, sizeof(int), nullptr}};
+    // every new buffer first; the context changes only when all of them exist (a failed call leaves the batch as it was)
+    hipError_t e = hipSuccess;
+    size_t failed_bytes = 0;
+    for (Row& r : rows) {
+        if ((e = hipMalloc(&r.fresh, B * nc * r.elem)) != hipSuccess) { failed_bytes = B * nc * r.elem; break; }
     }
+    if (e == hipSuccess)
+        for (Tab& t : tabs) {
+            const size_t bytes = B * ((size_t)hmask + 1) * t.elem;
+            if (*t.p && *t.cap >= bytes) continue;
+            if ((e = hipMalloc(&t.fresh, bytes)) != hipSuccess) { failed_bytes = bytes; break; }
+        }
+    if (e == hipSuccess)
+        for (Row& r : rows)
+            if ((e = hipMemcpy2D(r.fresh, nc * r.elem, *r.p, oc * r.elem, oc * r.elem, B, hipMemcpyDeviceToDevice)) != hipSuccess) break;
+    std::vector<int> stats(B * ST_COUNT);
+    if (e == hipSuccess) e = hipMemcpy(stats.data(), ctx->d_stats, stats.size() * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        for (size_t b = 0; b < B; ++b)
+            if (stats[b * ST_COUNT + ST_STOP] == STOP_CAPACITY) stats[b * ST_COUNT + ST_STOP] = STOP_RUNNING;
+        e = hipMemcpy(ctx->d_stats, stats.data(), stats.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        for (Row& r : rows) if (r.fresh) (void)hipFree(r.fresh);
+        for (Tab& t : tabs) if (t.fresh) (void)hipFree(t.fresh);
+        return fail(ctx, failed_bytes ? HSCMP_ERR_ALLOC : HSCMP_ERR_HIP, "hscmp_grow_events: %s (%zu bytes)", hipGetErrorString(e), failed_bytes);
+    }
+    for (Row& r : rows) { (void)hipFree(*r.p); *r.p = r.fresh; *r.cap = B * nc * r.elem; }
+    for (Tab& t : tabs) if (t.fresh) { if (*t.p) (void)hipFree(*t.p); *t.p = t.fresh; *t.cap = B * ((size_t)hmask + 1) * t.elem; }
     ctx->cap = new_max_events; ctx->P.cap = new_max_events; ctx->P.hmask = hmask; ctx->last.max_events = new_max_events;
     return HSCMP_OK;
 }
@@ -954,6 +969,104 @@ extern "C" int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slo
     return HSCMP_OK;
 }
 
+// ---- epilogue of the hierarchical encoder on the device (hscmp_epilogue.h) -----------------------------------------
+static int epi_buffer(hscmp_ctx* ctx, int i, size_t bytes)
+{
+    if (ctx->d_epi[i] && ctx->cap_epi[i] >= bytes) return HSCMP_OK;
+    if (ctx->d_epi[i]) { (void)hipFree(ctx->d_epi[i]); ctx->d_epi[i] = nullptr; ctx->cap_epi[i] = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&ctx->d_epi[i], want);
+    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    ctx->cap_epi[i] = want;
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int first, const hscmp_epilogue_level* levels, int nlevels,
+                                        double min_coefficients, const int64_t* offsets, int32_t* out_n, int32_t* out_colptr,
+                                        int32_t* out_indices, double* out_data, void* out_events, double* out_residual)
+{
+    if (!last || !level0) return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: NULL context");
+    if (!last->have_batch || !level0->have_batch) return fail(last, HSCMP_ERR_STATE, "hscmp_hierarchy_epilogue: no batch encoded");
+    if (last->device != level0->device) return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: contexts on different GPUs");
+    if (!levels || nlevels < 1 || nlevels > kEpiMaxLevels || !offsets || !out_n || !out_colptr || !out_indices || !out_data)
+        return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: bad arguments");
+    const int count = last->B, T = last->T, Fd = level0->F, Ktot = last->K;
+    if (first < 0 || first + count > level0->B || level0->T != T) return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: signal range / length mismatch");
+    if (!level0->last_x_dev) return fail(last, HSCMP_ERR_STATE, "hscmp_hierarchy_epilogue: the level-0 input is not on the device any more");
+    if (Ktot >= (1 << kEpiColBits) || T >= (1 << kEpiTBits) || last->cap >= (1 << kEpiIdxBits))
+        return fail(last, HSCMP_ERR_UNSUPPORTED, "hscmp_hierarchy_epilogue: shape outside the key layout (K < 2^20, T < 2^24, list < 2^20)");
+    HIP_TRY(last, hipSetDevice(last->device));
+    HIP_TRY(last, hipStreamSynchronize(level0->stream));
+    HIP_TRY(last, hipStreamSynchronize(last->stream));
+    const long long total = offsets[count];
+    EpiArgs A{};
+    A.nlevels = nlevels; A.Ktot = Ktot; A.T = T; A.Fd = Fd;
+    A.has_min = !std::isnan(min_coefficients); A.minc = A.has_min ? min_coefficients : 0.0;
+    // representations: one device buffer, level after level
+    size_t rep_bytes = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const hscmp_epilogue_level& d = levels[l];
+        if (d.col1 > d.col0 && (!d.rep || d.scale <= 0 || d.col1 > Ktot || d.col0 < 0)) return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: bad level %d", l);
+        rep_bytes += ((size_t)std::max(0, d.col1) * std::max(0, d.scale) * Fd * (d.rep_is_f32 ? 4 : 8) + 15) / 16 * 16;
+    }
+    int rc;
+    if ((rc = epi_buffer(last, 0, std::max<size_t>(16, rep_bytes)))) return rc;
+    size_t ro = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const hscmp_epilogue_level& d = levels[l];
+        EpiLevel& L = A.lv[l];
+        L.col0 = d.col0; L.col1 = d.col1; L.scale = d.scale; L.lead = (d.scale - 1) / 2; L.rep_f32 = d.rep_is_f32; L.rep = nullptr;
+        if (d.col1 <= d.col0) continue;
+        const size_t nb = (size_t)d.col1 * d.scale * Fd * (d.rep_is_f32 ? 4 : 8);       // rows [0, col1): indexed by the column number
+        L.rep = (char*)last->d_epi[0] + ro;
+        HIP_TRY(last, hipMemcpyAsync((char*)last->d_epi[0] + ro, d.rep, nb, hipMemcpyHostToDevice, last->stream));
+        ro += (nb + 15) / 16 * 16;
+        A.max_back = std::max(A.max_back, d.scale - 1 - L.lead);
+        A.max_fwd = std::max(A.max_fwd, L.lead);
+    }
+    int nmax = 2;
+    while (nmax < last->cap) nmax <<= 1;
+    const bool need_scratch = nmax > kEpiLdsKeys;
+    const size_t nres = out_residual ? (size_t)count * T * Fd * sizeof(double) : 0;
+    const size_t sizes[8] = {0, (size_t)(count + 1) * sizeof(long long), (size_t)count * sizeof(int), (size_t)count * (Ktot + 1) * sizeof(int),
+                             std::max<size_t>(16, (size_t)total * sizeof(int)), std::max<size_t>(16, (size_t)total * sizeof(double)),
+                             std::max<size_t>(16, (out_events ? (size_t)total * 16 : 0) + nres),
+                             need_scratch ? (size_t)count * nmax * sizeof(unsigned long long) : 0};
+    for (int i = 1; i < 8; ++i) if (sizes[i] && (rc = epi_buffer(last, i, sizes[i]))) return rc;
+    HIP_TRY(last, hipMemcpyAsync(last->d_epi[1], offsets, sizes[1], hipMemcpyHostToDevice, last->stream));
+    A.slot_t = last->d_slot_t; A.slot_k = last->d_slot_k; A.slot_a = last->d_slot_a; A.stats = last->d_stats; A.cap = last->cap;
+    A.offsets = (const long long*)last->d_epi[1]; A.out_n = (int*)last->d_epi[2]; A.out_colptr = (int*)last->d_epi[3];
+    A.out_indices = (int*)last->d_epi[4]; A.out_data = (double*)last->d_epi[5];
+    A.out_events = out_events ? (int*)last->d_epi[6] : nullptr;
+    A.out_residual = out_residual ? (double*)((char*)last->d_epi[6] + (out_events ? ((size_t)total * 16 + 15) / 16 * 16 : 0)) : nullptr;
+    if (out_events && out_residual && (rc = epi_buffer(last, 6, ((size_t)total * 16 + 15) / 16 * 16 + nres))) return rc;
+    A.out_events = out_events ? (int*)last->d_epi[6] : nullptr;
+    A.out_residual = out_residual ? (double*)((char*)last->d_epi[6] + (out_events ? ((size_t)total * 16 + 15) / 16 * 16 : 0)) : nullptr;
+    A.scratch = (unsigned long long*)last->d_epi[7]; A.scratch_n = nmax;
+    const size_t lds = (size_t)std::min(nmax, kEpiLdsKeys) * sizeof(unsigned long long);
+    const size_t xoff = (size_t)first * T * Fd * esize(level0->dtype);
+    if (level0->dtype == HSCMP_F32) {
+        auto kern = hier_epilogue_kernel<float>;
+        HIP_TRY(last, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(count), dim3(kEpiThreads), lds, last->stream, A, (const float*)((const char*)level0->last_x_dev + xoff));
+    } else {
+        auto kern = hier_epilogue_kernel<double>;
+        HIP_TRY(last, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(count), dim3(kEpiThreads), lds, last->stream, A, (const double*)((const char*)level0->last_x_dev + xoff));
+    }
+    HIP_TRY(last, hipGetLastError());
+    HIP_TRY(last, hipMemcpyAsync(out_n, A.out_n, sizes[2], hipMemcpyDeviceToHost, last->stream));
+    HIP_TRY(last, hipMemcpyAsync(out_colptr, A.out_colptr, sizes[3], hipMemcpyDeviceToHost, last->stream));
+    if (total > 0) {
+        HIP_TRY(last, hipMemcpyAsync(out_indices, A.out_indices, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, last->stream));
+        HIP_TRY(last, hipMemcpyAsync(out_data, A.out_data, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, last->stream));
+        if (out_events) HIP_TRY(last, hipMemcpyAsync(out_events, A.out_events, (size_t)total * 16, hipMemcpyDeviceToHost, last->stream));
+    }
+    if (out_residual) HIP_TRY(last, hipMemcpyAsync(out_residual, A.out_residual, nres, hipMemcpyDeviceToHost, last->stream));
+    HIP_TRY(last, hipStreamSynchronize(last->stream));
+    return HSCMP_OK;
+}
+
 #ifdef HSCMP_DBG_STAMPS
 extern "C" int hscmp_debug_blocks(unsigned long long* out, int n)
 {
@@ -1085,6 +1198,7 @@ extern "C" int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void*
     if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_update_inner_products: ctx is NULL");
     if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_update_inner_products: no dictionary set");
     if (!ip || !residual || T <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_update_inner_products: bad arguments");
+    if (p < 0 || p >= T) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_update_inner_products: atom centre %d outside the signal [0, %d)", p, T);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ctx->dtype == HSCMP_F32 ? run_update_rows<float>(ctx, ip, residual, T, p) : run_update_rows<double>(ctx, ip, residual, T, p);
 }

@@ -142,15 +142,22 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             e.close()
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
-                                 returnDistributed=True, chained=True, memoryBudget=None):
+                                 returnDistributed=True, chained=True, memoryBudget=None, epilogue='device', returnEvents=False,
+                                 deviceInput=None):
         """Batch form (the reference has no batch axis): `sequences` [B,T] (or [B,T,F]); every level encodes
         many signals per GPU call.  chained=True keeps the level hand-off on the device
         (hscmp_encode_batch_from_level): the dense [T, K_prev] float64 input of a level (modeling.py:1489)
         is scattered from the previous level's coefficient slots in GPU memory, in chunks of signals
         that fit `memoryBudget` bytes (default: 60 % of the GPU's memory) -- at BASELINE config 4 that input is 134 MB per signal and can
         not travel through the host.  chained=False builds the dense inputs on the host (small cases).
+        epilogue='device' (chained only): redistribution of the singleton columns (:1556-1594), CSC assembly (:1171-1181),
+        residual through the input-level representations (:1596-1611) and the event records (dataset.py:798-811) come
+        from ONE kernel per chunk over the last level's device-resident coefficient slots (hscmp_hierarchy_epilogue) and
+        are fetched once; 'host' assembles them signal by signal on the CPU (same results bit for bit).
+        deviceInput: device address of `sequences` ([B,T,F] in the level-0 compute dtype) when they already sit in GPU
+        memory (chained only); the host array is then used for its shape and dtype only.
         Returns (per-signal lists of per-level coefficient matrices, residuals [B,T(,F)] float64,
-        per-level kernel timings)."""
+        per-level kernel timings); with returnEvents=True a fourth item: per-signal event record arrays."""
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
             # LoCOMP is a host-driven loop around the GPU hooks: signal by signal
@@ -171,6 +178,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             weights[:nbSingletons] = singletonWeight                   # :1448-1450
             return D, weights, targetSnr, float(np.finfo(D.dtype).eps)
 
+        device_epilogue = chained and epilogue == 'device'
+
         def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
             params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
@@ -188,16 +197,19 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 eng.grow_events(maxEvents)
                 eng.continue_rounds(0)
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])
-            st, sk, sa = eng.fetch_slots()
             K = eng.K
-            if lazy:
-                # (the CSC assembly joins the per-signal host epilogue, which runs on all cores)
-                out = [(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+            if device_epilogue:
+                out = None                                     # the coefficient slots stay on the device (hscmp_hierarchy_epilogue)
             else:
-                out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+                st, sk, sa = eng.fetch_slots()
+                if lazy:
+                    # (the CSC assembly joins the per-signal host epilogue, which runs on all cores)
+                    out = [(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
+                else:
+                    out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
             tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
                       selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()))
-            return out, tm
+            return out, tm, stats
 
         per_level = [[None] * B for _ in range(nbLevels)]
         timings = []
@@ -214,40 +226,68 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
         else:
             engines = self._level_engines(nbLevels)      # kept across calls: their workspaces are tens of GB
-            if True:
-                # level 0: the signals themselves, all B at once
-                D, weights, targetSnr, eps = level_setup(0)
-                dt = _compute_dtype(sequences.dtype, D.dtype)
-                x = np.ascontiguousarray(np.asarray(sequences).reshape((B, T, -1)), dtype=dt)
-                D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt)
-                engines[0].set_dictionary(D3, np.asarray(weights, dtype=dt))
-                per_level[0], tm = run_level(engines[0], lambda p: engines[0].encode_batch(x, p), B, targetSnr, eps, lazy=True)
-                tm['level'] = 0
-                timings.append(tm)
-                setups = [None] + [level_setup(l) for l in range(1, nbLevels)]
-                fmax = 1
-                for l in range(1, nbLevels):
-                    Dl, wl = setups[l][0], setups[l][1]
-                    engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
-                    fmax = max(fmax, Dl.shape[2])
-                    timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, chunks=0))
-                if memoryBudget is None:
-                    memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
-                # per signal on the device: the dense float64 residual [T, F] (the input is scattered straight into it) + per-row state
-                chunk = int(max(1, min(B, memoryBudget // (1.05 * T * fmax * 8 + 160 * T))))
-                for first in range(0, B if nbLevels > 1 else 0, chunk):
-                    count = min(chunk, B - first)
+            # level 0: the signals themselves, all B at once
+            D, weights, targetSnr, eps = level_setup(0)
+            dt = _compute_dtype(sequences.dtype, D.dtype)
+            x = np.ascontiguousarray(np.asarray(sequences).reshape((B, T, -1)), dtype=dt)
+            D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)), dtype=dt)
+            engines[0].set_dictionary(D3, np.asarray(weights, dtype=dt))
+            if deviceInput is not None:
+                assert np.asarray(sequences).dtype == dt, 'deviceInput must hold the level-0 compute dtype'
+                enc0 = lambda p: engines[0].encode_batch_device(int(deviceInput), B, T, p)
+            else:
+                enc0 = lambda p: engines[0].encode_batch(x, p)
+            per_level[0], tm, stats0 = run_level(engines[0], enc0, B, targetSnr, eps, lazy=True)
+            tm['level'] = 0
+            timings.append(tm)
+            setups = [None] + [level_setup(l) for l in range(1, nbLevels)]
+            for l in range(1, nbLevels):
+                Dl, wl = setups[l][0], setups[l][1]
+                engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
+                timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, chunks=0))
+            if memoryBudget is None:
+                memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
+            # Per signal on the device, for EVERY level >= 1 at once (each level's engine keeps its workspace while the chunk
+            # moves up the hierarchy): the dense float64 residual [T, F_l] (the input is scattered straight into it), per-row
+            # state, and the event / slot / hash lists (about 80 bytes per list entry, sized from the level-0 counts).
+            nin0 = int(stats0[:, _native.STAT_SLOTS].max()) if B else 0
+            per_signal = sum(1.05 * T * setups[l][0].shape[2] * 8 + 160 * T + 80.0 * max(4096, 2 * nin0) for l in range(1, nbLevels))
+            chunk = int(max(1, min(B, memoryBudget // max(per_signal, 1.0)))) if nbLevels > 1 else B
+            results = [None] * B
+            first = 0
+            while first < B and (nbLevels > 1 or device_epilogue):
+                count = min(chunk, B - first)
+                try:
+                    last_stats = stats0
                     for l in range(1, nbLevels):
                         _, _, targetSnr, eps = setups[l]
                         prev, pfirst = (engines[0], first) if l == 1 else (engines[l - 1], 0)
                         # every input non-zero is explained at least once (by its singleton): size the lists for that
-                        nin = int(prev.fetch_stats()[pfirst:pfirst + count, _native.STAT_SLOTS].max())
-                        coefs, tm = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
-                                              count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64), lazy=True)
-                        per_level[l][first:first + count] = coefs
+                        nin = int(last_stats[pfirst:pfirst + count, _native.STAT_SLOTS].max())
+                        coefs, tm, last_stats = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
+                                                          count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64), lazy=True)
+                        if coefs is not None:
+                            per_level[l][first:first + count] = coefs
                         acc = timings[l]
                         acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['chunks'] += 1
                         acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
+                except _native.HscmpError as ex:
+                    # out of device memory part-way through a chunk (the budget is an estimate): halve the chunk, run it again
+                    if ex.code == _native.ERR_ALLOC and count > 1:
+                        chunk = max(1, count // 2)      # (the timing totals keep what the failed attempt had already run)
+                        continue
+                    raise
+                if device_epilogue:
+                    slot_counts = (stats0 if nbLevels == 1 else last_stats)[(first if nbLevels == 1 else 0):(first if nbLevels == 1 else 0) + count, _native.STAT_SLOTS]
+                    self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents)
+                first += count
+            if device_epilogue:
+                residuals = np.stack([r[1] for r in results], axis=0)
+                if np.asarray(sequences).ndim == 2:
+                    residuals = residuals[:, :, 0]
+                out = ([r[0] for r in results], residuals, timings)
+                return out + ([r[2] for r in results],) if returnEvents else out
+
         # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
         # kernels it spends its time in release the interpreter lock
         def finish(b):
@@ -263,7 +303,50 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         else:
             done = [finish(b) for b in range(B)]
         coefficients = [d[0] for d in done]
-        return coefficients, np.stack([d[1] for d in done], axis=0), timings
+        out = (coefficients, np.stack([d[1] for d in done], axis=0), timings)
+        if returnEvents:
+            from .dataset import convertSparseMatricesToEvents
+            out = out + ([convertSparseMatricesToEvents(c) for c in coefficients],)
+        return out
+
+    def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents):
+        """hscmp_hierarchy_epilogue for one chunk: per signal the per-level coefficient matrices (:1556-1634), the residual
+        (:1596-1611) and the event records (dataset.py:798-811), from the last level's device-resident slots."""
+        import scipy.sparse
+        last = engines[nbLevels - 1]
+        reps = multilevelDict.getMultiscaleDictionaries()
+        counts = [int(multilevelDict.getRawDictionary(l).shape[0]) for l in range(nbLevels)]
+        levels = []
+        for l in range(nbLevels):
+            if returnDistributed:
+                c0 = counts[l - 1] if l > 0 else 0         # level l owns the columns its own (non-singleton) atoms sit in
+                levels.append((c0, counts[l], reps[l]))
+            else:
+                levels.append((0, counts[l], reps[l]) if l == nbLevels - 1 else (0, 0, None))
+        n, colptr, offsets, indices, data, events, residual = last.hierarchy_epilogue(
+            engines[0], first if nbLevels > 1 else 0, levels, 1e-16, slot_counts, want_events=returnEvents)
+        T = residual.shape[1]
+        # per-level column pointers of the whole chunk at once: level l is the slice [c0, c1) of the last level's columns
+        ptrs, starts = [], []
+        for l, (c0, c1, _) in enumerate(levels):
+            if c1 <= c0:
+                ptrs.append(None); starts.append(None)
+                continue
+            base = colptr[:, c0:c0 + 1]
+            p = np.clip(colptr[:, :counts[l] + 1] - base, 0, None)
+            np.minimum(p, (colptr[:, c1:c1 + 1] - base), out=p)
+            ptrs.append(np.ascontiguousarray(p, dtype=np.int32)); starts.append(base[:, 0])
+        for b in range(count):
+            o = int(offsets[b])
+            mats = []
+            for l in range(nbLevels):
+                if ptrs[l] is None:
+                    mats.append(scipy.sparse.csc_matrix((T, counts[l]), dtype=np.float64))
+                    continue
+                lo = o + int(starts[l][b]); hi = lo + int(ptrs[l][b, -1])
+                mats.append(scipy.sparse.csc_matrix((data[lo:hi], indices[lo:hi], ptrs[l][b]), shape=(T, counts[l]), copy=False))
+            ev = events[o:o + int(n[b])] if events is not None else None
+            results[first + b] = (mats, residual[b], ev)
 
     def computeCoefficientsFromLevel(self, sequence, coefficients, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None,
                                      toleranceSnr=None, nbBlocks=1, minCoefficients=None, singletonWeight=0.5, stopCondition=None,

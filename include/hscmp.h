@@ -157,6 +157,33 @@ int hscmp_host_overlap_add(double* signal, int64_t T, int Fd, const int64_t* row
 int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slot_k, const double* slot_a, int64_t n, int K,
                             double min_coefficients, int32_t* indptr, int32_t* indices, double* data);
 
+/* Epilogue of the hierarchical encoder, on the device, for the `count` signals the LAST level's context `last` holds
+ * (signals [first, first + count) of the level-0 context `level0`, whose input must still be resident -- it is after
+ * hscmp_encode_batch; after hscmp_encode_batch_device the caller's buffer must still be valid).  From the last level's
+ * accumulated coefficients (its distinct (t, column) slots) it produces, per signal:
+ *   - the CSC form of modeling.py:1171-1181 (zeros and |c| < min_coefficients dropped; NaN: no clip): row indices and
+ *     float64 values in column-major order, and column pointers over the last level's columns; level l of the
+ *     "distributed" result (convertToDistributedCoefficients, modeling.py:1556-1594) owns columns [col0, col1) of it
+ *     under the same column numbers;
+ *   - the event records of dataset.py:798-811, (int32 time, int32 level, int32 index, float32 value), sorted by time,
+ *     then level, then index (out_events may be NULL);
+ *   - the residual of modeling.py:1596-1611, x - sum_l reconstructSignal(level l, levels[l].rep) in float64, every sum
+ *     in the order of the reference's sequential overlap-add (bit-identical to hscmp_host_overlap_add level by level;
+ *     out_residual [count][T][Fd] may be NULL).
+ * levels[l].rep: host pointer to the input-level patterns [>= col1][scale][Fd] of level l (getMultiscaleDictionaries),
+ * float32 (rep_is_f32 != 0) or float64.  offsets [count + 1] (host): entry offset of every signal in the packed outputs
+ * out_indices / out_data / out_events (offsets[b + 1] - offsets[b] >= that signal's slot count); out_n [count] receives
+ * the entries actually written per signal, out_colptr [count][K_last + 1] the column pointers. */
+typedef struct hscmp_epilogue_level {
+    int32_t col0, col1;    /* columns of the last level's matrix that belong to this level; col1 <= col0: none */
+    int32_t scale;         /* taps of the level's input-level patterns */
+    int32_t rep_is_f32;
+    const void* rep;
+} hscmp_epilogue_level;
+int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int first, const hscmp_epilogue_level* levels, int nlevels,
+                             double min_coefficients, const int64_t* offsets, int32_t* out_n, int32_t* out_colptr,
+                             int32_t* out_indices, double* out_data, void* out_events, double* out_residual);
+
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)
  * between rounds.  max_rounds <= 0: until converged. */

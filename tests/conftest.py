@@ -21,9 +21,12 @@ def _gpu_available():
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU: fail loudly rather than silently pass on nothing
     if _gpu_available():
         return
+    # `-m gpu` (the GPU tier) on a box without a GPU must not pass on nothing: fail loudly
+    markexpr = (config.getoption('-m') or '').strip()
+    if markexpr == 'gpu':
+        raise pytest.UsageError('the GPU tests were requested (-m gpu) but no MI355X is visible: torch.cuda.is_available() is False')
     skip = pytest.mark.skip(reason='no GPU visible')
     for item in items:
         if 'gpu' in item.keywords:

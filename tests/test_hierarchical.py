@@ -254,3 +254,33 @@ def test_hierarchical_batch_with_locomp_runs_signal_by_signal():
         for l in range(3):
             assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(c1[l])).nnz == 0
         assert np.array_equal(residuals[b], r1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('distributed', [True, False])
+def test_device_epilogue_equals_host_epilogue(distributed):
+    """hscmp_hierarchy_epilogue (redistribution, CSC, events, residual on the device) against the host epilogue
+    (hscmp_host_slots_to_csc + scipy column slicing + hscmp_host_overlap_add): coefficient matrices, event records and
+    the float64 residual bit for bit; 3 levels, several chunks."""
+    from hsc_amd.dataset import convertSparseMatricesToEvents
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+    z = _golden()
+    mld = _mld().withSingletonBases()
+    rs = np.random.RandomState(19)
+    base = z['x']
+    xs = np.stack([base, base[::-1].copy(), (0.7 * base + 0.05 * rs.standard_normal(base.shape)).astype(np.float32),
+                   (base * np.float32(1.3)), np.roll(base, 37)])
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9, returnDistributed=distributed)
+    for budget in (64e9, 2.5e6):
+        cd, rd, _, ed = hcmp.computeCoefficientsBatch(xs, mld, memoryBudget=budget, epilogue='device', returnEvents=True, **kw)
+        ch, rh, _, eh = hcmp.computeCoefficientsBatch(xs, mld, memoryBudget=budget, epilogue='host', returnEvents=True, **kw)
+        assert rd.shape == rh.shape and rd.dtype == rh.dtype and np.array_equal(rd, rh)
+        for b in range(xs.shape[0]):
+            for l in range(3):
+                a, h = scipy.sparse.csc_matrix(cd[b][l]), scipy.sparse.csc_matrix(ch[b][l])
+                assert a.shape == h.shape and (a != h).nnz == 0, (b, l)
+                assert np.array_equal(a.indptr, h.indptr) and np.array_equal(a.indices, h.indices) and np.array_equal(a.data, h.data)
+            assert ed[b].dtype == eh[b].dtype and np.array_equal(ed[b], eh[b]), b
+            assert np.array_equal(ed[b], convertSparseMatricesToEvents(cd[b]))
+    hcmp.close()

@@ -27,14 +27,18 @@ def build(scales, overcomplete=4, decompositionSize=3, seed=5, patience=1000, co
                         multilevelDecomposition=False, maxNbPatternsConsecutiveRejected=patience, nonNegativity=False)
 
 
-def signals(mld, nbSignals, nbSamples, rate=5e-4, compression=0.25, seed=5):
-    """One event stream + rendered signal per index, each from its own RandomState stream."""
-    xs, evs, rates = [], [], None
-    for b in range(nbSignals):
+def signals(mld, nbSignals, nbSamples, rate=5e-4, compression=0.25, seed=5, first=0):
+    """One event stream + rendered signal per index first .. first+nbSignals-1, each from its own RandomState stream
+    (shard-invariant).  The common rate scaling for the target compression ratio (hsc/dataset.py:686-706) is estimated
+    once: it depends on the dictionary and the length only."""
+    xs, evs = [], []
+    rates = rate * np.ones(mld.getNbLevels())
+    if compression is not None:
+        rates = SignalGenerator(mld, rates)._estimateOptimalRates(compression, nbSamples)
+    for b in range(first, first + nbSignals):
         rs = np.random.RandomState((0x48534300 + seed) * 1000003 % (2 ** 31) + b)
-        gen = SignalGenerator(mld, rate * np.ones(mld.getNbLevels()), rng=rs)
-        res = gen.generateEvents(nbSamples, compression)
-        events, rates = res if compression is not None else (res, gen.rates)
+        gen = SignalGenerator(mld, rates, rng=rs)
+        events = gen.generateEvents(nbSamples)
         xs.append(gen.generateSignalFromEvents(events, nbSamples=nbSamples))
         evs.append(events)
     return np.stack(xs), evs, rates
