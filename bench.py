@@ -112,8 +112,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-transfers', action='store_true', help='skip the PCIe-inclusive leg')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI) or 'gloo' (rehearsal)")
-    ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the CPU baseline (0 = one per usable core, at most 64)')
-    ap.add_argument('--cpu-signals-per-proc', type=int, default=4, help='signals each CPU process encodes (~3 s each)')
+    ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the CPU baseline (0 = one per usable core, at most 16: the CPU share of one GPU; the port is memory-bound and slows down beyond that)')
+    ap.add_argument('--cpu-signals-per-proc', type=int, default=2, help='signals each CPU process encodes (~3-6 s each)')
     ap.add_argument('--profile-steps', type=int, default=5, help='extra untimed steps used for per-kernel HIP-event timing')
     ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -355,7 +355,7 @@ def bench_cmp(args, ctx):
     if check and not all(check.values()):
         out['config']['output_check']['FAILED'] = True
     if world == 1 and not args.no_cpu_baseline:
-        nproc = args.cpu_procs or min(64, host_cores())
+        nproc = args.cpu_procs or min(16, host_cores())
         out['cpu_baseline'] = run_cpu_baseline(cfg, nproc, args.cpu_signals_per_proc)
     return out
 

@@ -206,7 +206,14 @@ class Engine(object):
         if w is not None and w.shape != (D3.shape[0],):
             raise ValueError('weights must have one entry per atom')
         K, W, F = D3.shape
+        # the same dictionary again (the row-level hooks of LoCOMP-style callers pass it with every call): nothing to upload
+        import zlib
+        key = (D3.shape, D3.dtype.str, zlib.crc32(D3.view(np.uint8).reshape(-1)), None if w is None else zlib.crc32(w.view(np.uint8)))
+        if key == getattr(self, '_dict_key', None):
+            return
+        self._dict_key = None
         self._check(self._lib.hscmp_set_dictionary(self._h, _ptr(D3), K, W, F, code, _ptr(w)), 'hscmp_set_dictionary')
+        self._dict_key = key
         self.dtype, self.K, self.W, self.F = D3.dtype, K, W, F
         self._batch = None
 

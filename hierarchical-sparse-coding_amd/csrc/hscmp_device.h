@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 
 namespace hscmp {
 
@@ -54,6 +55,13 @@ __device__ __forceinline__ void lds_barrier()
 //             share the CU's write-through vector cache.
 // Every wave of the group must pass the same sequence of barriers.
 // ------------------------------------------------------------------------------------------------
+// index of a thread inside the 256 threads that work on its signal (256-thread kernels: threadIdx.x itself; the
+// compiler knows the range from __launch_bounds__ and drops the mask)
+// With several signals per workgroup the waves of signal i are rotated by i roles: the wave that does a signal's
+// one-lane bookkeeping (and every other per-wave role) then sits on a different SIMD for each of the four signals,
+// instead of all four on one.
+__device__ __forceinline__ int ltid() { return (int)((threadIdx.x + ((threadIdx.x >> 8) << 6)) & 255u); }
+
 struct HwSync {
     static constexpr int kGroup = 1;
     __device__ __forceinline__ void lds() { lds_barrier(); }
@@ -88,7 +96,7 @@ struct SoftSync {
     __device__ __forceinline__ int count(int pred)
     {
         const int n = __popcll(__ballot(pred != 0));
-        if ((threadIdx.x & 255) == 0) *cnt = 0;
+        if (ltid() == 0) *cnt = 0;
         full();
         if ((threadIdx.x & 63) == 0 && n) atomicAdd(cnt, n);
         lds();
@@ -97,10 +105,6 @@ struct SoftSync {
         return total;
     }
 };
-
-// index of a thread inside the 256 threads that work on its signal (256-thread kernels: threadIdx.x itself; the
-// compiler knows the range from __launch_bounds__ and drops the mask)
-__device__ __forceinline__ int ltid() { return (int)(threadIdx.x & 255u); }
 
 constexpr int kEdgeWords = 4;    // per signal: left mask, right mask, stale sample index + 1 (0: none), its saved bits
 constexpr int kThreads = 256;   // one workgroup = 4 waves of 64
@@ -129,8 +133,6 @@ struct DevParams {
     unsigned hmask;     // slots of the per-signal (t,k) -> coefficient-slot hash table, minus one (power of two >= 2*cap)
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
-    int cus;            // compute units of the device (start stagger of co-resident workgroups)
-    int stagger;        // cycles by which consecutive signals of one workgroup start apart (kGroup > 1 policies)
 };
 
 // table size of the slot hash: load factor <= 1/2 whatever the event list holds
@@ -221,22 +223,46 @@ template <int CTRL> __device__ __forceinline__ void argmax_step(Cand<float>& c)
     o.i = dpp_i<CTRL>(c.i);
     if (better(o, c)) c = o;
 }
+// Scores are >= 0 (or -1 for "nothing"), so the arg-max splits into two plain reductions, each ONE fused DPP
+// instruction per step (v_max_f32_dpp / v_min_i32_dpp: the vector ALU is the resource the f32 MFMA shares, so
+// instruction count is what matters here): the wave maximum of the score, then the smallest index among the lanes that
+// hold it.  Steps: quad swaps, half-row and row mirrors (every row of 16 holds its result), row_bcast 15 / 31 (rows
+// 1..3 fold in their predecessors: lane 63 holds the wave's result), v_readlane.  Same winner as `better` picks.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_max_step(float v)
+{
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+    return fmaxf(v, o);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_min_step(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xF, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)      // v >= -1, no NaN; result in every lane (wave-uniform)
+{
+    v = dpp_max_step<0xB1, 0xF>(v);
+    v = dpp_max_step<0x4E, 0xF>(v);
+    v = dpp_max_step<0x141, 0xF>(v);
+    v = dpp_max_step<0x140, 0xF>(v);
+    v = dpp_max_step<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = dpp_min_step<0xB1, 0xF>(v);
+    v = dpp_min_step<0x4E, 0xF>(v);
+    v = dpp_min_step<0x141, 0xF>(v);
+    v = dpp_min_step<0x140, 0xF>(v);
+    v = dpp_min_step<0x142, 0xA>(v);
+    v = dpp_min_step<0x143, 0xC>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 template <> __device__ __forceinline__ Cand<float> wave_argmax<float>(Cand<float> c)
 {
-    argmax_step<0xB1>(c);     // quad_perm [1,0,3,2]
-    argmax_step<0x4E>(c);     // quad_perm [2,3,0,1]
-    argmax_step<0x141>(c);    // row_half_mirror
-    argmax_step<0x140>(c);    // row_mirror: every row of 16 lanes now holds its arg-max
     Cand<float> r;
-    r.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 0));
-    r.i = __builtin_amdgcn_readlane(c.i, 0);
-#pragma unroll
-    for (int row = 1; row < 4; ++row) {
-        Cand<float> o;
-        o.s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.s), 16 * row));
-        o.i = __builtin_amdgcn_readlane(c.i, 16 * row);
-        if (better(o, r)) r = o;
-    }
+    r.s = wave_max_f32(c.s);
+    r.i = wave_min_i32(c.s == r.s ? c.i : INT_MAX);
     return r;
 }
 
@@ -250,15 +276,45 @@ template <typename R> __device__ __forceinline__ R wave_max(R v)
 // Pinned summation tree (DESIGN.md "Numerics", oracle hsco_energy_*): the caller has formed the
 // 256 strided partials p[tid]; halving tree inside each wave, then (P0+P1)+(P2+P3).
 // Returns the total in thread 0 (other threads: unspecified).  `scratch` holds >= 2*kWaves R's.
-template <typename R, typename SY> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch, SY& sy)
+// Halving tree of the pinned sums inside one wave: lane i += lane i+m for m = 32, 16, 8, 4, 2, 1; the total ends in
+// lane 0 (the other lanes hold partial garbage nobody reads).  float: the partner comes through v_permlane32_swap /
+// v_permlane16_swap and row_shl DPP adds instead of six ds_bpermute round trips; same operands, same order.
+__device__ __forceinline__ void wave_tree_down2(float& a, float& b)
+{
+    {
+        const auto ra = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(a), false, false);
+        const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_int(b), __float_as_int(b), false, false);
+        a = a + __int_as_float((int)ra[1]);
+        b = b + __int_as_float((int)rb[1]);
+    }
+    {
+        const auto ra = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(a), false, false);
+        const auto rb = __builtin_amdgcn_permlane16_swap(__float_as_int(b), __float_as_int(b), false, false);
+        a = a + __int_as_float((int)ra[1]);
+        b = b + __int_as_float((int)rb[1]);
+    }
+#define HSCMP_TREE_STEP(CTRL)                                                                                                   \
+    a = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));                            \
+    b = b + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), CTRL, 0xF, 0xF, true));
+    HSCMP_TREE_STEP(0x108)      // row_shl:8
+    HSCMP_TREE_STEP(0x104)
+    HSCMP_TREE_STEP(0x102)
+    HSCMP_TREE_STEP(0x101)
+#undef HSCMP_TREE_STEP
+}
+__device__ __forceinline__ void wave_tree_down2(double& a, double& b)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        R oa = __shfl_down(a, m);
-        R ob = __shfl_down(b, m);
+        const double oa = __shfl_down(a, m), ob = __shfl_down(b, m);
         a = a + oa;
         b = b + ob;
     }
+}
+
+template <typename R, typename SY> __device__ __forceinline__ void pinned_tree2(R& a, R& b, R* scratch, SY& sy)
+{
+    wave_tree_down2(a, b);
     const int lane = ltid() & 63, wv = ltid() >> 6;
     sy.lds();                                           // (scratch lives in LDS: no need to drain global stores here)
     if (lane == 0) { scratch[wv] = a; scratch[kWaves + wv] = b; }

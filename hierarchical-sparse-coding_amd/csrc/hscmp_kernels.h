@@ -810,22 +810,8 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
 
-    // Signals that share a workgroup run the same program on the same SIMDs: started together they stay in lockstep
-    // (the matrix pipe is shared fairly, so they finish their tiles together and then all sit in their serial phases
-    // together, with the pipe idle).  The phase offset a signal starts with persists, so signal i of the workgroup is
-    // held back by i tile times: while one signal selects / updates, the tiles of the others keep the pipe busy.
-    if constexpr (GS > 1) {
-        const int slot = b - (int)blockIdx.x * GS;
-        const int naps = (slot * P.stagger + 8127) / 8128;              // s_sleep 127 = 127 x 64 cycles
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_setprio(3);                                  // (serial code above the other signals' tiles: hscmp_mfma.h)
-    } else if constexpr (Recorr::kFused) {
-        // two workgroups per CU (b and b + #CUs share one in the first round): the second starts half a period late
-        if (P.stagger > 0 && ((b / P.cus) & 1)) {
-            const int naps = (P.stagger + 8127) / 8128;
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
+    // several signals per workgroup: a signal's serial code outranks the other signals' tiles (hscmp_mfma.h, apply_atom)
+    if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
 
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
@@ -845,7 +831,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 }
                 c = wave_argmax(c);
                 const int sg = c.i;
-                p_sel = sh.seg_t[sg];
+                p_sel = __builtin_amdgcn_readfirstlane(sh.seg_t[sg]);
                 if constexpr (Recorr::kScoreOnly) {
                     nsel = 1;              // (k, c) and the null test (:974) are resolved inside apply_atom
                 } else {

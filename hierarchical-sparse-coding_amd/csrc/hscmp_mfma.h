@@ -796,7 +796,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                                                       SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved, Sync& sy)
     {
         (void)S;
-        const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = tid >> 6;
+        // p (and k, c once known) are wave-uniform: telling the compiler moves the span / segment arithmetic that
+        // derives from them to the scalar unit (the vector ALU is what the f32 MFMA competes for)
+        p = __builtin_amdgcn_readfirstlane(p);
+        const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int S4 = S4C > 0 ? S4C : A.S4;
         const Layout L = layout(P, A, lds);
         if (sh.nev >= P.cap) {                                  // event list full (uniform: LDS value)
@@ -819,6 +822,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         const int segbase = (sg0 << P.seg_shift);
         const int nsb = min(T, ((sg1 + 1) << P.seg_shift)) - segbase;    // positions of the touched segments
 
+        if (resolved) { k = __builtin_amdgcn_readfirstlane(k); c = wave_bcast(c, 0); }
         // ---- phase A: every global load of this atom, issued together -------------------------
         R rv[2]; int rm[2];
 #pragma unroll
@@ -867,7 +871,8 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             c = sh.red[0];
 #pragma unroll
             for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) { m = sh.cred[q]; c = sh.red[q]; }
-            k = m.i;
+            k = __builtin_amdgcn_readfirstlane(m.i);
+            c = wave_bcast(c, 0);
             if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
                 // (with a residual-scale rule the reference tests that rule first, :1145-1153: the slow rules name the reason)
                 if (tid == 0) { sh.converged = 1; sh.nullsel = 1; if (!P.has_scale && sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
@@ -934,12 +939,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         {
             R pb = (R)0, pa = (R)0;
             if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const R ob = __shfl_down(pb, m), oa = __shfl_down(pa, m);
-                pb = pb + ob;
-                pa = pa + oa;
-            }
+            wave_tree_down2(pb, pa);
             if (lane == 0) { sh.red[wv] = pb; sh.red[kWaves + wv] = pa; }
         }
         HSCMP_STAMP(2);                                         // energy partials
@@ -1083,11 +1083,6 @@ static int mfma_launch_iterate_g(hipStream_t stream, const DevParams& P0, const 
     set_segments(P, Pol::kMaxSegments);
     size_t lds = Pol::total_lds_bytes(P, A);
     if (GS > 1 && lds > (size_t)160 * 1024) return -1;
-    // one tile = (K/32 groups) x (W/2 MFMAs) x 64 cycles = K x W cycles of the matrix pipe
-    P.stagger = (int)std::min<int64_t>((int64_t)A.G * 32 * A.S4 * 8 * 11 / 10, 1 << 20);
-    P.cus = mfma_device_cus();
-    if (GS == 1) P.stagger = 0;
-    if (const char* e = getenv("HSCMP_STAGGER")) P.stagger = atoi(e);            // diagnostic
     if (const char* pad = getenv("HSCMP_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: force a lower occupancy
     auto kern = iterate_kernel<typename Tile::R, Pol>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;

@@ -88,6 +88,22 @@ def convertEventsToSparseMatrices(events, counts, sequenceLength):
     return out
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """Unpickler for dictionary files written by the reference (module `hsc.dataset`, Python 2) or by this package."""
+
+    def __init__(self, f):
+        pickle.Unpickler.__init__(self, f, encoding='latin1')
+
+    def find_class(self, module, name):
+        if module in ('hsc.dataset', 'hsc_amd.dataset') and name == 'MultilevelDictionary':
+            return MultilevelDictionary
+        if module == 'copy_reg':                      # Python-2 name of copyreg (old-style instance reconstruction)
+            module = 'copyreg'
+        if module == '__builtin__':
+            module = 'builtins'
+        return pickle.Unpickler.find_class(self, module, name)
+
+
 class MultilevelDictionary(object):
     """hsc/dataset.py:110-410 (container part)."""
 
@@ -219,10 +235,24 @@ class MultilevelDictionary(object):
 
     @staticmethod
     def restore(filePath):
+        """hsc/dataset.py:378-387.  Reads dictionaries saved by this package AND by the reference itself: the reference
+        pickles an `hsc.dataset.MultilevelDictionary` (Python 2 cPickle, protocol 2), so the class path is mapped to this
+        module and Python-2 byte strings (numpy array buffers) are decoded as latin-1."""
+        import os
+        filePath = os.path.abspath(filePath)
+        _, fmt = os.path.splitext(filePath)
+        if fmt != '.pkl' and fmt != '.p':
+            raise Exception('Unsupported format: %s' % (fmt))
         with open(filePath, 'rb') as f:
-            return pickle.load(f)
+            return _ReferenceUnpickler(f).load()
 
     def save(self, filePath):
+        """hsc/dataset.py:389-396"""
+        import os
+        filePath = os.path.abspath(filePath)
+        _, fmt = os.path.splitext(filePath)
+        if fmt != '.pkl' and fmt != '.p':
+            raise Exception('Unsupported format: %s' % (fmt))
         with open(filePath, 'wb') as f:
             pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
 

@@ -124,3 +124,60 @@ def test_generated_signal_is_recovered_by_the_hierarchical_encoder():
     assert coefficients[1].nnz > 0 and coefficients[1].shape == (4096, mld.withSingletonBases().counts[1])
     rec = hcsc.reconstruct(coefficients)
     assert np.allclose(rec + residual, x, atol=1e-4)
+
+
+# ---- dictionary files (hsc/dataset.py:378-396) ------------------------------------------------------------------------
+def test_restore_dictionary_saved_by_the_reference(tmp_path):
+    """tests/golden/mld_reference.pkl was written by the REAL reference's MultilevelDictionary (class path `hsc.dataset`,
+    pickle protocol 2, tools/make_golden.py mldpkl): it restores into this package's container with the same content."""
+    import os
+    import golden_util as gu
+    from hsc_amd.dataset import MultilevelDictionary
+    z = gu.load('hsc_small.npz')
+    m = MultilevelDictionary.restore(os.path.join(gu.GOLDEN, 'mld_reference.pkl'))
+    assert isinstance(m, MultilevelDictionary) and m.getNbLevels() == 3 and m.hasSingletonBases
+    assert np.array_equal(m.counts, z['counts']) and np.array_equal(m.countsNoSingletons, z['countsNoSingletons'])
+    for l in range(3):
+        assert np.array_equal(m.getRawDictionary(l), z['single_raw%d' % l])
+        assert np.array_equal(m.getMultiscaleDictionaries()[l], z['single_rep%d' % l])
+    # save / restore round trip, and the reference's extension rule
+    path = os.path.join(str(tmp_path), 'again.p')
+    m.save(path)
+    m2 = MultilevelDictionary.restore(path)
+    assert all(np.array_equal(a, b) for a, b in zip(m.dictionaries, m2.dictionaries))
+    with pytest.raises(Exception, match='Unsupported format'):
+        m.save(os.path.join(str(tmp_path), 'dict.npz'))
+    with pytest.raises(Exception, match='Unsupported format'):
+        MultilevelDictionary.restore(os.path.join(str(tmp_path), 'dict.json'))
+
+
+def test_restore_python2_style_pickle(tmp_path):
+    """What Python 2's cPickle actually writes: byte strings as (SHORT_)BINSTRING opcodes -- numpy array buffers among
+    them -- and `copy_reg` / `__builtin__` module names.  Emulated by a pickler that emits those opcodes."""
+    import os
+    import pickle
+    import struct
+    import golden_util as gu
+    from hsc_amd.dataset import MultilevelDictionary
+
+    class Py2Pickler(pickle._Pickler):
+        def save_bytes(self, obj):
+            n = len(obj)
+            self.write((b'U' + bytes([n]) if n < 256 else b'T' + struct.pack('<i', n)) + obj)
+            self.memoize(obj)
+        dispatch = dict(pickle._Pickler.dispatch)
+        dispatch[bytes] = save_bytes
+
+    src = MultilevelDictionary.restore(os.path.join(gu.GOLDEN, 'mld_reference.pkl'))
+    path = os.path.join(str(tmp_path), 'py2.pkl')
+    with open(path, 'wb') as f:
+        Py2Pickler(f, protocol=2).dump(src)
+    raw = open(path, 'rb').read()
+    raw = raw.replace(b'chsc_amd.dataset\n', b'chsc.dataset\n').replace(b'ccopyreg\n', b'ccopy_reg\n')
+    open(path, 'wb').write(raw)
+    with pytest.raises(Exception):
+        pickle.loads(raw)                                  # a plain load cannot: unknown module / undecodable byte strings
+    m = MultilevelDictionary.restore(path)
+    assert all(np.array_equal(a, b) for a, b in zip(src.dictionaries, m.dictionaries))
+    assert all(np.array_equal(a, b) for a, b in zip(src.representations, m.representations))
+    assert np.array_equal(src.counts, m.counts) and m.hasSingletonBases

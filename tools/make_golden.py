@@ -408,6 +408,31 @@ def gen_hsc_config4():
     print('wrote hsc_config4.npz', os.path.getsize(os.path.join(OUT, 'hsc_config4.npz')), 'bytes')
 
 
+def gen_mld_pickle():
+    """A multilevel dictionary (with singleton bases) saved by the REAL reference's MultilevelDictionary.save
+    (dataset.py:389-396; cPickle protocol 2 under Python 2): tests/golden/mld_reference.pkl.  Data only: the class is
+    pickled by reference (module path `hsc.dataset`), the arrays by value."""
+    import pickle
+    import types
+    ref = load_reference()
+    z = np.load(os.path.join(OUT, 'hsc_small.npz'))
+    mld = ref.dataset.MultilevelDictionary.fromRawDictionaries([z['raw0'], z['raw1'], z['raw2']], [int(v) for v in z['scales']])
+    mlds = mld.withSingletonBases()
+    saved = {k: sys.modules.get(k) for k in ('hsc', 'hsc.dataset')}
+    sys.modules.setdefault('hsc', types.ModuleType('hsc'))
+    sys.modules['hsc.dataset'] = ref.dataset              # the in-memory module the loader built: lets pickle resolve the class path
+    try:
+        with open(os.path.join(OUT, 'mld_reference.pkl'), 'wb') as f:
+            pickle.dump(mlds, f, protocol=2)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    print('wrote mld_reference.pkl', os.path.getsize(os.path.join(OUT, 'mld_reference.pkl')), 'bytes')
+
+
 def gen_locomp():
     """LoCOMP (modeling.py:1191-1425) on small seeded problems."""
     ref = load_reference()
@@ -555,7 +580,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'hsc4', 'locomp', 'synth', 'learn']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'hsc4', 'mldpkl', 'locomp', 'synth', 'learn']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -568,6 +593,8 @@ if __name__ == '__main__':
         gen_hsc_medium()
     if 'hsc4' in which:
         gen_hsc_config4()
+    if 'mldpkl' in which:
+        gen_mld_pickle()
     if 'locomp' in which:
         gen_locomp()
     if 'synth' in which:
