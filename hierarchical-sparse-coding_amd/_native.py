@@ -208,7 +208,8 @@ class Engine(object):
         K, W, F = D3.shape
         # the same dictionary again (the row-level hooks of LoCOMP-style callers pass it with every call): nothing to upload
         import zlib
-        key = (D3.shape, D3.dtype.str, zlib.crc32(D3.view(np.uint8).reshape(-1)), None if w is None else zlib.crc32(w.view(np.uint8)))
+        key = (D3.shape, D3.dtype.str, zlib.crc32(D3.view(np.uint8).reshape(-1)), None if w is None else zlib.crc32(w.view(np.uint8)),
+               tuple(sorted(kv for kv in os.environ.items() if kv[0].startswith('HSCMP_'))))    # (diagnostic switches read at upload)
         if key == getattr(self, '_dict_key', None):
             return
         self._dict_key = None

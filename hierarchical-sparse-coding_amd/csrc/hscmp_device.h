@@ -35,6 +35,14 @@ __device__ unsigned long long g_cnt[16];         // free-form event counters of 
 #endif
 
 
+// analysis build only (-DHSCMP_MARKS): comment lines in the assembly that delimit the source phases, so that
+// tools/count_marks.py can attribute instruction counts; emits no instruction
+#ifdef HSCMP_MARKS
+#define HSCMP_MARK(name) asm volatile("; HSCMP_MARK " name ::: "memory")
+#else
+#define HSCMP_MARK(name) do {} while (0)
+#endif
+
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
 // outstanding global stores (vmcnt), which costs a full memory round trip per barrier
 __device__ __forceinline__ void lds_barrier()
@@ -71,20 +79,34 @@ struct HwSync {
 
 struct SoftSync {
     static constexpr int kGroup = 4;
-    unsigned* bar;        // LDS: arrivals so far (monotone; compared modulo 2^32)
+    unsigned addr;        // LDS byte address of the counter (monotone, compared modulo 2^32); wave-uniform
     int* cnt;             // LDS: scratch of count()
-    unsigned target;      // 4 x barriers passed by this wave (wave-uniform)
+    unsigned target;      // counter value once all four waves have arrived at this wave's current barrier (wave-uniform)
+    // Hand-written: the vector ALU is what the other signals' f32 MFMA tiles compete for, and the compiler's form of
+    // "one lane adds, all lanes poll" costs 7 + 3 x polls vector instructions per barrier.  Here the arrival is scalar
+    // code around one ds_add (EXEC narrowed to lane 0; the increment is the counter's own address -- any non-zero
+    // constant does, and that one is already in a register), and a poll is ds_read + v_readfirstlane.
+    __device__ __forceinline__ void init(unsigned* bar, int* cnt_)
+    {
+        addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)bar);
+        cnt = cnt_;
+        target = 0u;
+    }
     __device__ __forceinline__ void arrive_and_wait()
     {
-        target += 4u;
-        asm volatile("" ::: "memory");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (;;) {
-            const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if ((int)(v - target) >= 0) break;
-            __builtin_amdgcn_s_sleep(1);
+        target = __builtin_amdgcn_readfirstlane(target) + 4u * addr;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %1\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(addr) : "memory");
+        for (int nap = 0;; ++nap) {               // look at once, then at growing intervals (64 .. 512 cycles)
+            unsigned v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
+            if (nap < 2) __builtin_amdgcn_s_sleep(1);
+            else if (nap < 4) __builtin_amdgcn_s_sleep(2);
+            else if (nap < 8) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(8);
         }
-        asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void lds() { arrive_and_wait(); }
     __device__ __forceinline__ void full()
@@ -228,41 +250,39 @@ template <int CTRL> __device__ __forceinline__ void argmax_step(Cand<float>& c)
 // instruction count is what matters here): the wave maximum of the score, then the smallest index among the lanes that
 // hold it.  Steps: quad swaps, half-row and row mirrors (every row of 16 holds its result), row_bcast 15 / 31 (rows
 // 1..3 fold in their predecessors: lane 63 holds the wave's result), v_readlane.  Same winner as `better` picks.
-template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_max_step(float v)
+// (hand-written: the compiler's form of a DPP reduction step is v_mov + v_mov_dpp + v_max -- three to four vector
+// instructions -- where one fused v_max_i32_dpp does; s_nop 1 covers the VALU-write -> DPP-read hazard.  Scores are
+// compared through their bit patterns: non-negative floats order like integers, and the "nothing" sentinel -1.0f is
+// a negative integer.)
+__device__ __forceinline__ int wave_max_i32(int v)          // result in every lane (wave-uniform)
 {
-    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
-    return fmaxf(v, o);
-}
-template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_min_step(int v)
-{
-    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xF, false);
-    return o < v ? o : v;
-}
-__device__ __forceinline__ float wave_max_f32(float v)      // v >= -1, no NaN; result in every lane (wave-uniform)
-{
-    v = dpp_max_step<0xB1, 0xF>(v);
-    v = dpp_max_step<0x4E, 0xF>(v);
-    v = dpp_max_step<0x141, 0xF>(v);
-    v = dpp_max_step<0x140, 0xF>(v);
-    v = dpp_max_step<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_max_step<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-    v = dpp_min_step<0xB1, 0xF>(v);
-    v = dpp_min_step<0x4E, 0xF>(v);
-    v = dpp_min_step<0x141, 0xF>(v);
-    v = dpp_min_step<0x140, 0xF>(v);
-    v = dpp_min_step<0x142, 0xA>(v);
-    v = dpp_min_step<0x143, 0xC>(v);
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 template <> __device__ __forceinline__ Cand<float> wave_argmax<float>(Cand<float> c)
 {
     Cand<float> r;
-    r.s = wave_max_f32(c.s);
-    r.i = wave_min_i32(c.s == r.s ? c.i : INT_MAX);
+    const int sb = __float_as_int(c.s);
+    const int mb = wave_max_i32(sb);
+    r.s = __int_as_float(mb);
+    r.i = wave_min_i32(sb == mb ? c.i : INT_MAX);
     return r;
 }
 

@@ -821,17 +821,25 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         int p_sel = 0, k_sel = 0;
         R c_sel = (R)0;
         if (!P.blocked) {
+            HSCMP_MARK("select");
             // :965-975 flat arg-max == arg-max over the segment maxima (ties: lowest t, then k)
             if constexpr (Recorr::kFused) {
-                // every wave scans all segment maxima redundantly: no cross-wave combine, no barrier
-                Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
-                for (int i = lane; i < P.nseg; i += 64) {
-                    Cand<R> o; o.s = sh.seg_score[i]; o.i = i;
-                    if (better(o, c)) c = o;
+                // ONE wave scans the segment maxima and publishes the position; the others wait at an LDS barrier.  (The
+                // vector ALU is what the f32 MFMA tiles of the co-resident signals compete for: three waves that wait cost
+                // a handful of instructions, three redundant scans cost ~270.)
+                if (wv == 0) {
+                    Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
+                    for (int i = lane; i < P.nseg; i += 64) {         // ascending i per lane: '>' keeps the first of equals
+                        const R sc = sh.seg_score[i];
+                        if (sc > c.s) { c.s = sc; c.i = i; }
+                    }
+                    c = wave_argmax(c);
+                    if (lane == 0) { sh.atom_t = sh.seg_t[c.i]; sh.atom_k = c.i; }
                 }
-                c = wave_argmax(c);
-                const int sg = c.i;
-                p_sel = __builtin_amdgcn_readfirstlane(sh.seg_t[sg]);
+                sy.lds();
+                p_sel = __builtin_amdgcn_readfirstlane(sh.atom_t);
+                const int sg = __builtin_amdgcn_readfirstlane(sh.atom_k);      // (the winning segment)
+                (void)sg;
                 if constexpr (Recorr::kScoreOnly) {
                     nsel = 1;              // (k, c) and the null test (:974) are resolved inside apply_atom
                 } else {
@@ -972,6 +980,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
             nsel = sh.nsel;
         }
 
+        HSCMP_MARK("after_select");
         if (P.select_only) {
             // _selectBestAtoms entry point (hscmp_select_best_atoms): the ordered list goes back as is
             if (tid == 0) {

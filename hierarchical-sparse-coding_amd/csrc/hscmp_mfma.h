@@ -652,7 +652,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     static __device__ __forceinline__ Sync make_sync(Shared& sh)
     {
         if constexpr (GS == 1) return HwSync();
-        else { SoftSync sy; sy.bar = &sh.bar; sy.cnt = &sh.bar_cnt; sy.target = 0u; return sy; }
+        else { SoftSync sy; sy.init(&sh.bar, &sh.bar_cnt); return sy; }
     }
 
     struct Layout {
@@ -823,6 +823,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         const int nsb = min(T, ((sg1 + 1) << P.seg_shift)) - segbase;    // positions of the touched segments
 
         if (resolved) { k = __builtin_amdgcn_readfirstlane(k); c = wave_bcast(c, 0); }
+        HSCMP_MARK("A_loads");
         // ---- phase A: every global load of this atom, issued together -------------------------
         R rv[2]; int rm[2];
 #pragma unroll
@@ -852,6 +853,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // signals longer than 131072 samples have segments of 512+ positions: the rest of the touched segments
         for (int i = tid + 2 * kThreads; i < nsb; i += kThreads) L.sbs[i] = Gs.bc[segbase + i];
 
+        HSCMP_MARK("resolve");
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {
             sy.lds();                                      // Bx: the position's window is in LDS
@@ -881,6 +883,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             }
         }
 
+        HSCMP_MARK("dupcheck");
         // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
         // Long slot lists (sh.hashed, see slot_find): the bookkeeping thread probes the hash table instead; its
         // first probe is in flight under the atom's work and is only looked at in the bookkeeping below.
@@ -899,6 +902,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             probe_key = hkey_load(Gs.hkey + probe_pos);
         }
 
+        HSCMP_MARK("residual");
         // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
         const R nc = -c;
 #pragma unroll
@@ -935,6 +939,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             sy.lds();                                      // B1: window, squares, segment buffer in LDS
         }
         HSCMP_STAMP(1);                                         // B1
+        HSCMP_MARK("energy");
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
         {
             R pb = (R)0, pa = (R)0;
@@ -944,6 +949,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         }
         HSCMP_STAMP(2);                                         // energy partials
 
+        HSCMP_MARK("tile");
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
         // Four waves per SIMD: the vector instructions of a signal's serial phases must not queue behind the MFMAs of
         // the three other signals (one issue slot per 64-cycle MFMA each, shared by age: measured 4.7x longer serial
@@ -964,6 +970,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         sy.lds();                                          // B4: per-row scores in the segment buffer
         HSCMP_STAMP(4);                                         // B4
 
+        HSCMP_MARK("segmax");
         // ---- maxima of the touched segments, out of LDS
         for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) {
             const int t0 = (sg << P.seg_shift), t1 = min(T, t0 + P.seg);
@@ -975,6 +982,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             best = wave_argmax(best);
             if (lane == 0) { sh.seg_score[sg] = best.s; sh.seg_t[sg] = best.i; }
         }
+        HSCMP_MARK("bookkeeping");
         // ---- bookkeeping and the fast stop rules (:1106-1142) on the bookkeeping thread
         int si = -1, ev = 0;
         bool new_slot = false;
@@ -1015,6 +1023,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                 if ((double)qv >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
             }
         }
+        HSCMP_MARK("B5");
         HSCMP_STAMP(5);                                         // segment maxima + bookkeeping
         sy.full();                                        // B5: also drains this atom's residual / score stores
         HSCMP_STAMP(6);                                         // B5
@@ -1032,6 +1041,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
 #ifdef HSCMP_DBG_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[15] += 1;
 #endif
+        HSCMP_MARK("atom_end");
         return sh.converged != 0;
     }
 };
