@@ -288,7 +288,8 @@ class Engine(object):
                                                             ctypes.byref(params)), 'hscmp_encode_batch_from_level')
         self._batch = (int(count), prev._batch[1], int(params.max_events))
 
-    def hierarchy_epilogue(self, level0, first, levels, minCoefficients, slot_counts, want_events=True, want_residual=True):
+    def hierarchy_epilogue(self, level0, first, levels, minCoefficients, slot_counts, want_events=True, want_residual=True,
+                           residual_out=None):
         """hscmp_hierarchy_epilogue on this (last-level) engine.  levels: list of (col0, col1, representations [K,scale(,Fd)]).
         slot_counts: int array [count], the slot count of every signal (stats[:, STAT_SLOTS]).
         Returns (n [count], colptr [count, K+1], offsets [count+1], indices, data, events or None, residual or None)."""
@@ -315,7 +316,11 @@ class Engine(object):
         indices = np.empty(max(total, 1), dtype=np.int32)
         data = np.empty(max(total, 1), dtype=np.float64)
         events = np.empty(max(total, 1), dtype=EVENT_DTYPE) if want_events else None
-        residual = np.empty((count, T, Fd), dtype=np.float64) if want_residual else None
+        if residual_out is not None:                 # the caller's [count, T, Fd] float64 slice (C-contiguous) is filled in place
+            assert residual_out.shape == (count, T, Fd) and residual_out.dtype == np.float64 and residual_out.flags.c_contiguous
+            residual = residual_out
+        else:
+            residual = np.empty((count, T, Fd), dtype=np.float64) if want_residual else None
         minc = float('nan') if minCoefficients is None else float(minCoefficients)
         self._check(self._lib.hscmp_hierarchy_epilogue(self._h, level0._h, int(first), arr, len(levels), ctypes.c_double(minc), _ptr(offsets),
                                                        _ptr(n), _ptr(colptr), _ptr(indices), _ptr(data), _ptr(events), _ptr(residual)),

@@ -182,6 +182,14 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     if (ctx->d_fval) { (void)hipFree(ctx->d_fval); ctx->d_fval = nullptr; }
     HIP_TRY(ctx, hipMalloc(&ctx->d_D, nD));
     HIP_TRY(ctx, hipMemcpy(ctx->d_D, D, nD, hipMemcpyHostToDevice));
+    // weights that are all exactly 1 select like no weights at all (|c * 1| == |c| bit for bit; the level-0 weights of the
+    // hierarchical encoder, modeling.py:1448-1450 with no singletons): the unweighted kernels are the cheaper instances
+    if (weights) {
+        bool all_one = true;
+        for (int k = 0; k < K && all_one; ++k)
+            all_one = dtype == HSCMP_F32 ? ((const float*)weights)[k] == 1.0f : ((const double*)weights)[k] == 1.0;
+        if (all_one) weights = nullptr;
+    }
     if (weights) {
         HIP_TRY(ctx, hipMalloc(&ctx->d_w, (size_t)K * es));
         HIP_TRY(ctx, hipMemcpy(ctx->d_w, weights, (size_t)K * es, hipMemcpyHostToDevice));

@@ -14,6 +14,9 @@
 
 namespace hscmp {
 
+#ifdef HSCMP_DBG_CHECKSEG
+#define HSCMP_DBG_STAMPS
+#endif
 #ifdef HSCMP_DBG_STAMPS
 // diagnostic build only (tools/read_stamps.py); never compiled into the product library
 __device__ unsigned long long g_stamps[64];      // per-phase cycle sums of workgroup 0: [0,16) fused atom body, [32,48) step-by-step body and sparse_rows

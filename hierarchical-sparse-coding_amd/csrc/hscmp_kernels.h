@@ -869,6 +869,26 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
             }
         } else {
             // :908-937 one arg-max per block of bs samples (half-block shifted when offset is set)
+#ifdef HSCMP_DBG_CHECKSEG
+            // diagnostic build: the segment maxima kept in LDS against a fresh scan of the score array
+            if constexpr (Recorr::kFused) {
+                for (int sg = wv; sg < P.nseg; sg += kWaves) {
+                    const int t0 = sg << P.seg_shift, t1 = min(T, t0 + P.seg);
+                    Cand<R> w = wave_range_argmax<Recorr::kScoreOnly>(G, wts, t0, t1, lane);
+                    if (w.i == INT_MAX) { w.i = t0; w.s = (R)0; }
+                    if (lane == 0 && (w.s != sh.seg_score[sg] || w.i != sh.seg_t[sg])) {
+                        const unsigned long long n = atomicAdd(&g_cnt[0], 1ull);
+                        if (n < 3) {
+                            g_cnt[4 + 4 * n + 0] = ((unsigned long long)b << 32) | (unsigned)sg;
+                            g_cnt[4 + 4 * n + 1] = ((unsigned long long)__float_as_uint((float)w.s) << 32) | __float_as_uint((float)sh.seg_score[sg]);
+                            g_cnt[4 + 4 * n + 2] = ((unsigned long long)(unsigned)w.i << 32) | (unsigned)sh.seg_t[sg];
+                            g_cnt[4 + 4 * n + 3] = ((unsigned long long)(unsigned)sh.rounds << 32) | (unsigned)sh.iters;
+                        }
+                    }
+                }
+                sy.lds();
+            }
+#endif
             const int off = sh.offset;
             const int nb = P.nbk + (off ? 1 : 0);
             const int pad0 = off ? P.bs / 2 : 0;

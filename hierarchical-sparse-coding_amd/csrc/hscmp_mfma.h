@@ -905,6 +905,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         HSCMP_MARK("residual");
         // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
         const R nc = -c;
+        bool own[2] = {false, false};                           // this thread owns the sample itself: it stores the new value
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * kThreads;
@@ -922,21 +923,28 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                             L.edge[3] = edge_bits_of(v);
                             L.edge[2] = (unsigned long long)(m + 1);
                         }
-                        Gs.r[m] = vn;
+                        own[u] = true;
                         L.esq[q] = v * v;
                         L.esq[L.wp + q] = vn * vn;
                     }
                     v = vn;
                 }
                 L.win[i] = v;
+                rv[u] = v;
             }
         }
         HSCMP_STAMP(0);                                         // phase A + resolve + update, up to B1
+        sy.lds();                                               // B1: window, squares, segment buffer in LDS
+        // The new samples go to memory only BEHIND this barrier.  Near a signal end a sample of the atom's support is
+        // loaded twice in phase A -- by its own thread and, through the reflection, by a thread of another wave -- and
+        // with blocked selection nothing else separates those loads from this store: a wave that left the previous
+        // barrier late would load the sample after it had changed and subtract the atom from it a second time.  Every
+        // thread has consumed what it loaded before it arrives here (its window entry depends on it).
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (own[u]) Gs.r[rm[u]] = rv[u];
         if (P.has_scale) {                                      // toleranceResidualScale: max|r| of touched segments
-            sy.full();                                    // B1 (+ residual stores visible to the scan)
+            sy.full();                                          // (the stores above are visible to the scan)
             for (int sg = (s >> P.seg_shift) + wv; sg <= ((e - 1) >> P.seg_shift); sg += kWaves) rscan_segment(P, Gs, sh, sg, lane);
-        } else {
-            sy.lds();                                      // B1: window, squares, segment buffer in LDS
         }
         HSCMP_STAMP(1);                                         // B1
         HSCMP_MARK("energy");
@@ -1040,6 +1048,45 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         HSCMP_STAMP(7);                                         // deferred stores
 #ifdef HSCMP_DBG_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[15] += 1;
+#endif
+#ifdef HSCMP_DBG_CHECKSEG
+        // diagnostic build: the re-correlated rows near the signal ends again, one thread per row, pinned chain from the (now final) residual
+        if (lo < 64 || hi >= T - 64) {
+            sy.full();
+            const int row = tid, t = p - (W - 1) + row;
+            if (row < nrows && t >= 0 && t < T) {
+                float best = 0.0f;
+                for (int kk = 0; kk < P.K; ++kk) {
+                    float acc = 0.0f;
+                    for (int w = 0; w < W; ++w)
+                        acc = fmaf((float)edge_window_value(Gs.r, T, t - P.off + w, t, L.edge), (float)L.dimg[Tile::dindex(kk, w, S4)], acc);
+                    if (HAS_W) acc = acc * (float)L.wts[kk];
+                    best = fmaxf(best, fabsf(acc));
+                }
+                const float kept = (float)Gs.bc[t];
+                if (best != kept) {
+                    const unsigned long long n = atomicAdd(&g_cnt[1], 1ull);
+                    if (n < 3) {
+                        g_cnt[4 + 4 * n + 0] = ((unsigned long long)(blockIdx.x * GS + (threadIdx.x >> 8)) << 32) | (unsigned)t | 0x80000000u;
+                        g_cnt[4 + 4 * n + 1] = ((unsigned long long)__float_as_uint(best) << 32) | __float_as_uint(kept);
+                        g_cnt[4 + 4 * n + 2] = ((unsigned long long)(unsigned)p << 32) | (unsigned)sh.iters;
+                        // first tap whose window sample differs from what the tile saw
+                        int wbad = -1; float we = 0.f, wg = 0.f;
+                        for (int w = 0; w < W && wbad < 0; ++w) {
+                            const float ex = (float)edge_window_value(Gs.r, T, t - P.off + w, t, L.edge);
+                            const float got = (float)L.win[row + w];
+                            if (ex != got) { wbad = w; we = ex; wg = got; }
+                        }
+                        int mfound = 0xffff;
+                        for (int mm = sidx; mm <= eidx; ++mm) if ((float)Gs.r[mm] == wg) { mfound = mm - sidx; break; }
+                        (void)we;
+                        g_cnt[4 + 4 * n + 3] = ((unsigned long long)(unsigned)(wbad & 0xffff) << 48) | ((unsigned long long)(unsigned)(mfound & 0xffff) << 32) | __float_as_uint(wg);
+                        g_cnt[4 + 4 * n + 2] = ((unsigned long long)(unsigned)p << 32) | (unsigned)(sidx & 0xffff) << 16 | (unsigned)(row & 0xffff);
+                    }
+                }
+            }
+            sy.full();
+        }
 #endif
         HSCMP_MARK("atom_end");
         return sh.converged != 0;

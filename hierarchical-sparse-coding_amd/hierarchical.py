@@ -254,6 +254,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             per_signal = sum(1.05 * T * setups[l][0].shape[2] * 8 + 160 * T + 80.0 * max(4096, 2 * nin0) for l in range(1, nbLevels))
             chunk = int(max(1, min(B, memoryBudget // max(per_signal, 1.0)))) if nbLevels > 1 else B
             results = [None] * B
+            residual_all = np.empty((B, T, x.shape[2]), dtype=np.float64) if device_epilogue else None
             first = 0
             while first < B and (nbLevels > 1 or device_epilogue):
                 count = min(chunk, B - first)
@@ -279,12 +280,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     raise
                 if device_epilogue:
                     slot_counts = (stats0 if nbLevels == 1 else last_stats)[(first if nbLevels == 1 else 0):(first if nbLevels == 1 else 0) + count, _native.STAT_SLOTS]
-                    self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents)
+                    self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents,
+                                          residual_all[first:first + count])
                 first += count
             if device_epilogue:
-                residuals = np.stack([r[1] for r in results], axis=0)
-                if np.asarray(sequences).ndim == 2:
-                    residuals = residuals[:, :, 0]
+                residuals = residual_all[:, :, 0] if np.asarray(sequences).ndim == 2 else residual_all
                 out = ([r[0] for r in results], residuals, timings)
                 return out + ([r[2] for r in results],) if returnEvents else out
 
@@ -309,7 +309,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             out = out + ([convertSparseMatricesToEvents(c) for c in coefficients],)
         return out
 
-    def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents):
+    def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents, residual_out):
         """hscmp_hierarchy_epilogue for one chunk: per signal the per-level coefficient matrices (:1556-1634), the residual
         (:1596-1611) and the event records (dataset.py:798-811), from the last level's device-resident slots."""
         import scipy.sparse
@@ -324,7 +324,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             else:
                 levels.append((0, counts[l], reps[l]) if l == nbLevels - 1 else (0, 0, None))
         n, colptr, offsets, indices, data, events, residual = last.hierarchy_epilogue(
-            engines[0], first if nbLevels > 1 else 0, levels, 1e-16, slot_counts, want_events=returnEvents)
+            engines[0], first if nbLevels > 1 else 0, levels, 1e-16, slot_counts, want_events=returnEvents, residual_out=residual_out)
         T = residual.shape[1]
         # per-level column pointers of the whole chunk at once: level l is the slice [c0, c1) of the last level's columns
         ptrs, starts = [], []
@@ -346,7 +346,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 lo = o + int(starts[l][b]); hi = lo + int(ptrs[l][b, -1])
                 mats.append(scipy.sparse.csc_matrix((data[lo:hi], indices[lo:hi], ptrs[l][b]), shape=(T, counts[l]), copy=False))
             ev = events[o:o + int(n[b])] if events is not None else None
-            results[first + b] = (mats, residual[b], ev)
+            results[first + b] = (mats, None, ev)
 
     def computeCoefficientsFromLevel(self, sequence, coefficients, multilevelDict, nbNonzeroCoefs=None, toleranceResidualScale=None,
                                      toleranceSnr=None, nbBlocks=1, minCoefficients=None, singletonWeight=0.5, stopCondition=None,

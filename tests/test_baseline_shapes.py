@@ -12,6 +12,8 @@
 
 CPU part: the oracle (as level coder of the host logic) against the same reference goldens, and reconstructSignal's
 dense branch (modeling.py:247-258) against the reference's fftconvolve result."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse
@@ -132,8 +134,21 @@ def test_config2_full_batch_1024():
         acc = scipy.sparse.coo_matrix((c.astype(np.float64), (t, k)), shape=(T, 256)).tocsc()
         assert abs(acc - res.coefficients[b]).max() <= 1e-12
         assert L0 - 2 <= res.coefficients[b].nnz <= L0      # (an accumulated coefficient may cancel to exactly zero)
-    # (iv) determinism at batch scale: a second run reproduces events, slots and residuals bit for bit
-    res2 = ConvolutionalMatchingPursuit().computeCoefficientsBatch(xs, D, nbNonzeroCoefs=L0)
+    # (iv) determinism at batch scale: a second run reproduces events, slots and residuals bit for bit -- once with the
+    # dispatcher's choice (four signals per workgroup at this batch size), once with one signal per workgroup
+    assert res.variant.endswith('_x4')
+    for force in (None, '0'):
+        if force is not None:
+            os.environ['HSCMP_MFMA_QUAD'] = force
+        try:
+            res2 = ConvolutionalMatchingPursuit().computeCoefficientsBatch(xs, D, nbNonzeroCoefs=L0)
+        finally:
+            os.environ.pop('HSCMP_MFMA_QUAD', None)
+        assert res2.variant.endswith('_x4') == (force is None)
+        _same_results(res, res2, B)
+
+
+def _same_results(res, res2, B):
     assert np.array_equal(res.stats, res2.stats) and np.array_equal(res.energies, res2.energies)
     assert np.array_equal(res.residuals, res2.residuals)
     for b in range(B):
@@ -183,12 +198,22 @@ def test_config4_real_dictionary_dims_packed_batch(monkeypatch):
                 recon[s:e] += c * reps[l][k][s - lo:e - lo].astype(np.float64)
         assert float(np.max(np.abs((xs[b] - recon) - residuals[b]))) <= 1e-9, b
     assert all(c[0].shape == (T, 256) and c[1].shape == (T, 384) for c in coefs)
-    # determinism at batch scale
-    coefs2, residuals2, _ = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
-    assert np.array_equal(residuals, residuals2)
-    for b in range(B):
-        for l in range(2):
-            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs2[b][l])).nnz == 0, (b, l)
+    # determinism at batch scale, and the four-signals-per-workgroup level-0 loop (dispatched here: B > 2 x CUs) against
+    # the one-signal-per-workgroup loop on ALL signals, then three more runs of the dispatched build.  (This comparison is what exposed
+    # the reflected-sample load/store race of the fused atom body: about one signal in a thousand)
+    assert timings[0]['variant'].endswith('_x4')
+    monkeypatch.setenv('HSCMP_MFMA_QUAD', '0')
+    coefs1, residuals1, t1 = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
+    assert not t1[0]['variant'].endswith('_x4')
+    monkeypatch.delenv('HSCMP_MFMA_QUAD')
+    assert np.array_equal(residuals, residuals1)
+    for rep in range(3):
+        coefs2, residuals2, _ = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
+        assert np.array_equal(residuals, residuals2), rep
+        for b in range(B):
+            for l in range(2):
+                assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs2[b][l])).nnz == 0, (rep, b, l)
+                assert rep or (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs1[b][l])).nnz == 0, (b, l)
     gpu.close()
 
 
