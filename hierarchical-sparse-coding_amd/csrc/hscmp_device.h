@@ -66,12 +66,34 @@ __device__ __forceinline__ void lds_barrier()
 //             share the CU's write-through vector cache.
 // Every wave of the group must pass the same sequence of barriers.
 // ------------------------------------------------------------------------------------------------
-// index of a thread inside the 256 threads that work on its signal (256-thread kernels: threadIdx.x itself; the
-// compiler knows the range from __launch_bounds__ and drops the mask)
-// With several signals per workgroup the waves of signal i are rotated by i roles: the wave that does a signal's
-// one-lane bookkeeping (and every other per-wave role) then sits on a different SIMD for each of the four signals,
-// instead of all four on one.
-__device__ __forceinline__ int ltid() { return (int)((threadIdx.x + ((threadIdx.x >> 8) << 6)) & 255u); }
+// index of a thread inside the 256 threads that work on its signal, and the signal of a thread inside its workgroup.
+// 256-thread kernels: threadIdx.x itself.  Four signals per 1024-thread workgroup: signal i owns threads 256i..256i+255
+// -- waves 4i..4i+3, which the hardware spreads over the four SIMDs (tools/simd_map_probe.hip: waves w, w+4, w+8, w+12
+// of a workgroup share a SIMD) -- and its waves are rotated by i roles, so that the wave that does a signal's one-lane
+// bookkeeping (and every other per-wave role) sits on a different SIMD for each of the four signals.
+// -DHSCMP_QUAD_SIMD_AFFINE=1 (measurement only) gives every signal one SIMD to itself instead (signal = wave & 3): its
+// serial phases then never meet another signal's matrix instructions, but its four waves also share one vector ALU
+// and nothing fills the matrix pipe of that SIMD meanwhile -- measured 10.7 ms against 9.6 ms for the greedy loop of
+// config 2.
+#ifndef HSCMP_QUAD_SIMD_AFFINE
+#define HSCMP_QUAD_SIMD_AFFINE 0
+#endif
+__device__ __forceinline__ int ltid()
+{
+#if HSCMP_QUAD_SIMD_AFFINE
+    return blockDim.x > 256u ? (int)(((threadIdx.x >> 8) << 6) | (threadIdx.x & 63u)) : (int)threadIdx.x;
+#else
+    return (int)((threadIdx.x + ((threadIdx.x >> 8) << 6)) & 255u);
+#endif
+}
+__device__ __forceinline__ int gsig()
+{
+#if HSCMP_QUAD_SIMD_AFFINE
+    return __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 3u));
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+#endif
+}
 
 struct HwSync {
     static constexpr int kGroup = 1;

@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     constexpr int GS = Recorr::kGroup;
     Recorr::prologue_shared(P, S, A, smem);              // (kGroup > 1: the shared image, behind a hardware barrier)
     // (wave-uniform by construction; readfirstlane tells the compiler, so the per-signal pointers live in SGPRs)
-    const int b = GS == 1 ? (int)blockIdx.x : (int)blockIdx.x * GS + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int b = GS == 1 ? (int)blockIdx.x : (int)blockIdx.x * GS + gsig();
     if (GS > 1 && b >= P.B) return;                      // (a ragged last workgroup; no hardware barrier from here on)
     char* sbase = smem + Recorr::signal_lds_offset(P, A);
     SH& sh = *reinterpret_cast<SH*>(sbase);
@@ -809,9 +809,6 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     int* ord_t = raw_t + P.maxsel; int* ord_k = raw_k + P.maxsel; R* ord_c = raw_c + P.maxsel;                                      // second half
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
-
-    // several signals per workgroup: a signal's serial code outranks the other signals' tiles (hscmp_mfma.h, apply_atom)
-    if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
 
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {

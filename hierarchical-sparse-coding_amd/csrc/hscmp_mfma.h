@@ -632,6 +632,15 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
     static constexpr int kGroup = GS;
+    // -DHSCMP_QUAD_LOCKSTEP=1 (measurement only): barriers B1 and B4 of the atom body become hardware barriers across
+    // the four signals of the workgroup, which lines their tiles up -- all serial phases then run together without a
+    // matrix instruction beside them, all tiles together.  Measured 10.1-10.2 ms against 9.6 ms for the greedy loop of
+    // config 2: what the serial phases gain by running alone (tools/serial_stretch_probe.hip) is less than what the
+    // matrix pipe loses by idling through them.
+#ifndef HSCMP_QUAD_LOCKSTEP
+#define HSCMP_QUAD_LOCKSTEP 0
+#endif
+    static constexpr bool kLockstep = GS > 1 && HSCMP_QUAD_LOCKSTEP != 0;
     static constexpr int kMinWavesPerSimd = GS;         // (launch bounds: 4 signals x 4 waves = 4 waves per SIMD)
     using Sync = typename std::conditional<GS == 1, HwSync, SoftSync>::type;
     static constexpr int kEnergyWaves = kWaves;
@@ -687,7 +696,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     static __device__ __forceinline__ int signal_lds_offset(const DevParams& P, const Args& A)
     {
         if constexpr (GS == 1) return 0;
-        else return (int)(shared_lds_bytes(A) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) * per_signal_lds_bytes(P, A));
+        else return (int)(shared_lds_bytes(A) + (size_t)gsig() * per_signal_lds_bytes(P, A));
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
@@ -853,6 +862,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // signals longer than 131072 samples have segments of 512+ positions: the rest of the touched segments
         for (int i = tid + 2 * kThreads; i < nsb; i += kThreads) L.sbs[i] = Gs.bc[segbase + i];
 
+        HSCMP_STAMP(8);                                         // phase A issued
         HSCMP_MARK("resolve");
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {
@@ -883,6 +893,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             }
         }
 
+        HSCMP_STAMP(9);                                         // resolve
         HSCMP_MARK("dupcheck");
         // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
         // Long slot lists (sh.hashed, see slot_find): the bookkeeping thread probes the hash table instead; its
@@ -934,7 +945,11 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             }
         }
         HSCMP_STAMP(0);                                         // phase A + resolve + update, up to B1
-        sy.lds();                                               // B1: window, squares, segment buffer in LDS
+        // B1: window, squares, segment buffer in LDS.  (Lockstep build: waves of a signal that has finished have ended
+        // and the hardware barrier does not count them; every wave passes exactly two hardware barriers per atom, B1
+        // and B4, and leaves the loop only between atoms, so all signals are always at the same one of the two.)
+        if constexpr (kLockstep) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else sy.lds();
         // The new samples go to memory only BEHIND this barrier.  Near a signal end a sample of the atom's support is
         // loaded twice in phase A -- by its own thread and, through the reflection, by a thread of another wave -- and
         // with blocked selection nothing else separates those loads from this store: a wave that left the previous
@@ -949,20 +964,19 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         HSCMP_STAMP(1);                                         // B1
         HSCMP_MARK("energy");
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
-        {
+        auto energy_partials = [&]() {
             R pb = (R)0, pa = (R)0;
             if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
             wave_tree_down2(pb, pa);
             if (lane == 0) { sh.red[wv] = pb; sh.red[kWaves + wv] = pa; }
-        }
+        };
+        if constexpr (!kLockstep) energy_partials();
         HSCMP_STAMP(2);                                         // energy partials
 
         HSCMP_MARK("tile");
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
-        // Four waves per SIMD: the vector instructions of a signal's serial phases must not queue behind the MFMAs of
-        // the three other signals (one issue slot per 64-cycle MFMA each, shared by age: measured 4.7x longer serial
-        // phases).  Serial code runs at priority 3 and takes every slot it can use; the tiles run at priority 0.
-        if constexpr (GS > 1) __builtin_amdgcn_s_setprio(0);
+        // (s_setprio does not help a signal's serial code against the other signals' tiles: measured, no effect --
+        // tools/serial_stretch_probe.hip.)
         for (int q = wv; q < ntiles; q += kWaves) {
             R sc;
             if constexpr (GS > 1 && S4C > 0) sc = Tile::template tile_score_lean<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
@@ -973,9 +987,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                 L.sbs[t - segbase] = sc;
             }
         }
-        if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
         HSCMP_STAMP(3);                                         // MFMA tile(s) of this wave
-        sy.lds();                                          // B4: per-row scores in the segment buffer
+        // B4: per-row scores in the segment buffer
+        if constexpr (kLockstep) { energy_partials(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else sy.lds();
         HSCMP_STAMP(4);                                         // B4
 
         HSCMP_MARK("segmax");
@@ -1067,7 +1082,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                 if (best != kept) {
                     const unsigned long long n = atomicAdd(&g_cnt[1], 1ull);
                     if (n < 3) {
-                        g_cnt[4 + 4 * n + 0] = ((unsigned long long)(blockIdx.x * GS + (threadIdx.x >> 8)) << 32) | (unsigned)t | 0x80000000u;
+                        g_cnt[4 + 4 * n + 0] = ((unsigned long long)(blockIdx.x * GS + gsig()) << 32) | (unsigned)t | 0x80000000u;
                         g_cnt[4 + 4 * n + 1] = ((unsigned long long)__float_as_uint(best) << 32) | __float_as_uint(kept);
                         g_cnt[4 + 4 * n + 2] = ((unsigned long long)(unsigned)p << 32) | (unsigned)sh.iters;
                         // first tap whose window sample differs from what the tile saw

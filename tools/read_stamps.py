@@ -17,11 +17,13 @@ for i in range(3):
     lib.hscmp_debug_stamps(out, 1)
     v = np.array(list(out), dtype=np.float64)
     n = max(v[15], 1)
-names = ['phaseA+update', 'B1', 'energy', 'MFMA tile', 'B4', 'seg+bookkeeping', 'B5', 'deferred stores']
+names = ['dup+update to B1', 'B1', 'energy', 'MFMA tile', 'B4', 'seg+bookkeeping', 'B5', 'deferred stores']
 print('B=%d atoms=%d loop %.3f ms' % (B, n, eng.last_kernel_ms()[2]))
 for i, nm in enumerate(names):
     print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
-print('  %-18s %8.0f cycles/atom (sum; the select between atoms is not stamped)' % ('total', v[:8].sum() / n))
+for i, nm in ((8, 'phase A issue'), (9, 'resolve (Bx..By)')):
+    print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
+print('  %-18s %8.0f cycles/atom (sum; the select between atoms is not stamped)' % ('total', (v[:8].sum() + v[8] + v[9]) / n))
 
 # per-workgroup residency (diagnostic build)
 try:
