@@ -22,7 +22,7 @@ STOP_RUNNING, STOP_CAPACITY = 0, 7
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
-           'hscmp_update_inner_products', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_hierarchy_epilogue', 'hscmp_encode_batch',
+           'hscmp_update_inner_products', 'hscmp_table_open', 'hscmp_table_select', 'hscmp_table_update', 'hscmp_table_read', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_hierarchy_epilogue', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
@@ -89,6 +89,10 @@ def load_library():
     lib.hscmp_select_best_atoms.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_double, vp, vp, vp, vp, ci,
                                             ctypes.POINTER(ctypes.c_int32)]
     lib.hscmp_update_inner_products.argtypes = [vp, vp, vp, ci, ci]
+    lib.hscmp_table_open.argtypes = [vp, vp, ci]
+    lib.hscmp_table_select.argtypes = [vp, ci, ci, ctypes.c_double, vp, vp, vp, vp, ci, ctypes.POINTER(ctypes.c_int32)]
+    lib.hscmp_table_update.argtypes = [vp, vp, ci, ci, vp, ci]
+    lib.hscmp_table_read.argtypes = [vp, vp, vp]
     lib.hscmp_assign_windows.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.hscmp_host_slots_to_csc.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_double, vp, vp, vp]
     lib.hscmp_host_overlap_add.argtypes = [vp, ctypes.c_int64, ci, vp, vp, vp, ctypes.c_int64, vp, ci, ci]
@@ -157,6 +161,19 @@ def make_params(nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=N
         tolerance_residual_scale=nan if toleranceResidualScale is None else float(toleranceResidualScale),
         null_coeff_thres=nan if minCoefficients is None else float(minCoefficients),
         eps=float(eps), max_events=int(maxEvents), max_rounds=int(maxRounds))
+
+
+class DeviceTable(object):
+    """Handle of the inner-product table kept on the device by Engine.table_open (LoCOMP's `innerProducts`).  Quacks
+    enough like the reference's ndarray for the coder's own use (shape, dtype); `read()` downloads it."""
+
+    def __init__(self, engine, T):
+        self.engine = engine
+        self.shape = (T, engine.K)
+        self.dtype = engine.dtype
+
+    def read(self):
+        return self.engine.table_read(table=True)[0]
 
 
 class Engine(object):
@@ -265,6 +282,43 @@ class Engine(object):
         self._check(self._lib.hscmp_update_inner_products(self._h, _ptr(innerProducts), _ptr(r), r.shape[0], int(position)),
                     'hscmp_update_inner_products')
         return innerProducts
+
+    # ---- LoCOMP's table, resident on the device (include/hscmp.h: hscmp_table_*) ----
+    def table_open(self, x):
+        """innerProducts = convolve1d(x, D, 'same') and residual := x, both kept on the device (modeling.py:1293)."""
+        r = np.ascontiguousarray(np.asarray(x).reshape((np.asarray(x).shape[0], -1)), dtype=self.dtype)
+        assert r.shape[1] == self.F
+        self._check(self._lib.hscmp_table_open(self._h, _ptr(r), r.shape[0]), 'hscmp_table_open')
+        self._table_T = r.shape[0]
+        return DeviceTable(self, r.shape[0])
+
+    def table_select(self, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
+        T = self._table_T
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=self.dtype)
+        cap = T + 2
+        t = np.empty(cap, dtype=np.int32)
+        k = np.empty(cap, dtype=np.int32)
+        c = np.empty(cap, dtype=self.dtype)
+        n = ctypes.c_int32(0)
+        thres = float('nan') if nullCoeffThres is None else float(nullCoeffThres)
+        self._check(self._lib.hscmp_table_select(self._h, nb_blocks_code(nbBlocks), int(bool(offset)), ctypes.c_double(thres), _ptr(w),
+                                                 _ptr(t), _ptr(k), _ptr(c), cap, ctypes.byref(n)), 'hscmp_table_select')
+        self._batch = None
+        return t[:n.value].copy(), k[:n.value].copy(), c[:n.value].copy()
+
+    def table_update(self, residual_rows, start, centres):
+        """residual[start:start+len(rows)] := rows on the device, then rows p-(W-1)..p+(W-1) of the table re-correlated
+        in place for every centre p (modeling.py:1018-1051)."""
+        rows = np.ascontiguousarray(np.asarray(residual_rows).reshape((len(residual_rows), -1)), dtype=self.dtype)
+        cs = np.ascontiguousarray(centres, dtype=np.int32)
+        self._check(self._lib.hscmp_table_update(self._h, _ptr(rows), int(start), rows.shape[0], _ptr(cs), cs.shape[0]), 'hscmp_table_update')
+
+    def table_read(self, table=True, residual=False):
+        T = self._table_T
+        tab = np.empty((T, self.K), dtype=self.dtype) if table else None
+        res = np.empty((T, self.F), dtype=self.dtype) if residual else None
+        self._check(self._lib.hscmp_table_read(self._h, _ptr(tab), _ptr(res)), 'hscmp_table_read')
+        return tab, res
 
     def encode_batch(self, x, params):
         """x [B,T,F] host array of the dictionary dtype."""

@@ -68,10 +68,14 @@ struct hscmp_ctx {
     bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
     bool mfma_state = false;        // the batch's table-free state is the score-only form of the MFMA kernels
     const void* last_x_dev = nullptr;   // device address of the signals of the last encode (hscmp_hierarchy_epilogue reads them)
-    // epilogue workspace (grow-only)
-    void* d_epi[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap_epi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // workspace arena of the entry points outside the batch encode (grow-only, lives as long as the context): slots
+    // 0-7 the hierarchical epilogue, 8-15 the row-level entry points and the device-resident table
+    void* d_epi[16] = {nullptr};
+    size_t cap_epi[16] = {0};
+    // device-resident inner-product table of LoCOMP (hscmp_table_*): [T][K] in slot kArenaTable, its residual in kArenaTabRes
+    int tab_T = 0;
 };
+enum { kArenaRowA = 8, kArenaRowB = 9, kArenaRowC = 10, kArenaRowD = 11, kArenaTable = 12, kArenaTabRes = 13, kArenaTabW = 14 };
 
 static thread_local std::string g_err;
 
@@ -94,6 +98,29 @@ static int fail(hscmp_ctx* ctx, int code, const char* fmt, ...)
     } while (0)
 
 static size_t esize(int dtype) { return dtype == HSCMP_F64 ? 8 : 4; }
+
+// Arena slot i holds at least `bytes` afterwards.  Grow-only: a call that fits reuses the buffer (no hipMalloc in the
+// steady state of any entry point); a call that does not fit waits for the stream (kernels may still read the old
+// buffer), frees and allocates 1/8 more than asked.  `keep`: the old contents are copied over.
+static int epi_buffer(hscmp_ctx* ctx, int i, size_t bytes, bool keep = false)
+{
+    if (ctx->d_epi[i] && ctx->cap_epi[i] >= bytes) return HSCMP_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    const size_t want = bytes + bytes / 8 + 256;
+    void* fresh = nullptr;
+    e = hipMalloc(&fresh, want);
+    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    if (ctx->d_epi[i]) {
+        if (keep && (e = hipMemcpy(fresh, ctx->d_epi[i], ctx->cap_epi[i], hipMemcpyDeviceToDevice)) != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(ctx, HSCMP_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(ctx->d_epi[i]);
+    }
+    ctx->d_epi[i] = fresh; ctx->cap_epi[i] = want;
+    return HSCMP_OK;
+}
 
 extern "C" int hscmp_version(void) { return HSCMP_VERSION; }
 
@@ -162,6 +189,7 @@ extern "C" int hscmp_synchronize(hscmp_ctx* ctx)
 
 extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W, int F, hscmp_dtype dtype, const void* weights)
 {
+    if (ctx) ctx->tab_T = 0;                               // a resident table belongs to the dictionary it was built with
     if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_set_dictionary: ctx is NULL");
     if (!D || K <= 0 || W <= 0 || F <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad shape K=%d W=%d F=%d", K, W, F);
     if (dtype != HSCMP_F32 && dtype != HSCMP_F64) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad dtype %d", (int)dtype);
@@ -280,17 +308,19 @@ extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W,
     return HSCMP_OK;
 }
 
-static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevParams* out)
+// geometry given explicitly (the row-level selection runs on a caller's table of any K, W: the context's dictionary is
+// not involved and is not touched)
+static int make_params_g(hscmp_ctx* ctx, int K, int W, int F, int B, int T, const hscmp_params* p, DevParams* out)
 {
     DevParams P{};
-    P.B = B; P.T = T; P.K = ctx->K; P.W = ctx->W; P.F = ctx->F;
-    P.off = (ctx->W - 1) / 2;
+    P.B = B; P.T = T; P.K = K; P.W = W; P.F = F;
+    P.off = (W - 1) / 2;
     set_segments(P, kMaxSeg);
     if (p->nb_blocks == 1) { P.blocked = 0; P.bs = 0; P.nbk = 0; P.maxsel = 1; }
     else {
         // modeling.py:908-918
         int bs;
-        if (p->nb_blocks < 0) bs = 4 * ctx->W;
+        if (p->nb_blocks < 0) bs = 4 * W;
         else if (p->nb_blocks > 1) bs = (int)std::floor((double)T / (double)p->nb_blocks);
         else return fail(ctx, HSCMP_ERR_INVALID, "nb_blocks must be 1, > 1 or -1 ('auto'), got %d", p->nb_blocks);
         if (bs % 2 == 1) bs += 1;
@@ -315,6 +345,11 @@ static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevP
     return HSCMP_OK;
 }
 
+static int make_params(hscmp_ctx* ctx, int B, int T, const hscmp_params* p, DevParams* out)
+{
+    return make_params_g(ctx, ctx->K, ctx->W, ctx->F, B, T, p, out);
+}
+
 // every buffer tracks its own capacity in bytes (element size changes with the dictionary dtype)
 struct BufCap { void** p; size_t* cap; size_t bytes; };
 
@@ -333,9 +368,14 @@ static int sparse_init_split(int B, int T, int W)
     return std::max(1, std::min(nblocks, (2048 + B - 1) / B));
 }
 
+static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, size_t es, bool multi_feature, bool row_lists);
 static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
 {
-    const size_t es = esize(ctx->dtype);
+    return ensure_workspace_g(ctx, P, need_x, esize(ctx->dtype), ctx->F > 1, use_row_lists(ctx));
+}
+// (element size and feature layout given explicitly: see make_params_g)
+static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, size_t es, bool multi_feature, bool row_lists)
+{
     const size_t B = P.B, TF = (size_t)P.T * P.F, T = P.T, cap = P.cap, ms = P.maxsel;
     BufCap bufs[] = {
         {(void**)&ctx->d_x, &ctx->caps[0], need_x ? B * TF * es : 0},
@@ -354,10 +394,10 @@ static int ensure_workspace(hscmp_ctx* ctx, const DevParams& P, bool need_x)
         {(void**)&ctx->d_stats, &ctx->caps[13], B * ST_COUNT * sizeof(int)},
         {(void**)&ctx->d_energy, &ctx->caps[14], B * 2 * es},
         {(void**)&ctx->d_edge, &ctx->caps[15], B * kEdgeWords * sizeof(unsigned long long)},
-        {(void**)&ctx->d_scratch, &ctx->cap_scratch, ctx->F > 1 ? B * (size_t)sparse_init_split(P.B, P.T, P.W) * (2 * P.W - 1) * P.K * es : 0},
-        {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, ctx->F > 1 ? B * T : 0},
-        {(void**)&ctx->d_rl_cnt, &ctx->cap_rl_cnt, use_row_lists(ctx) ? B * T * sizeof(int) : 0},
-        {(void**)&ctx->d_rl_f, &ctx->cap_rl_f, use_row_lists(ctx) ? B * T * kRowListCap * sizeof(int) : 0},
+        {(void**)&ctx->d_scratch, &ctx->cap_scratch, multi_feature ? B * (size_t)sparse_init_split(P.B, P.T, P.W) * (2 * P.W - 1) * P.K * es : 0},
+        {(void**)&ctx->d_rowflag, &ctx->cap_rowflag, multi_feature ? B * T : 0},
+        {(void**)&ctx->d_rl_cnt, &ctx->cap_rl_cnt, row_lists ? B * T * sizeof(int) : 0},
+        {(void**)&ctx->d_rl_f, &ctx->cap_rl_f, row_lists ? B * T * kRowListCap * sizeof(int) : 0},
         {(void**)&ctx->d_hkey, &ctx->cap_hkey, B * ((size_t)P.hmask + 1) * sizeof(unsigned long long)},
         {(void**)&ctx->d_hval, &ctx->cap_hval, B * ((size_t)P.hmask + 1) * sizeof(int)},
     };
@@ -829,33 +869,32 @@ extern "C" int hscmp_mem_info(hscmp_ctx* ctx, uint64_t* free_bytes, uint64_t* to
 extern "C" const char* hscmp_last_variant(hscmp_ctx* ctx) { return ctx ? ctx->variant.c_str() : ""; }
 
 // modeling.py:149-188 convolve1d on the GPU: full table out [Tout][K]
+template <typename R> static void launch_convolve(hscmp_ctx* ctx, const R* dx, int T, int same, int Tout, R* dout)
+{
+    DevParams P{};
+    P.B = 1; P.T = T; P.K = ctx->K; P.W = ctx->W; P.F = ctx->F; P.off = (ctx->W - 1) / 2;
+    State<R> S{};
+    S.D = (const R*)ctx->d_D; S.weights = nullptr;
+    S.Dc = ctx->d_Dc ? (const R*)ctx->d_Dc : (const R*)ctx->d_D;
+    dim3 grid((Tout + kThreads - 1) / kThreads, 1);
+    hipLaunchKernelGGL((corr_init_generic_kernel<R, true>), grid, dim3(kThreads), 0, ctx->stream, P, S, dx, same ? P.off : 0, Tout, dout);
+}
+
 template <typename R> static int run_convolve(hscmp_ctx* ctx, const void* x, int T, int same, void* out)
 {
     const int K = ctx->K, W = ctx->W, F = ctx->F;
     const int Tout = same ? T : T - W + 1;
     if (Tout <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_convolve1d: T=%d shorter than the filters (W=%d)", T, W);
-    R* dx = nullptr; R* dout = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&dx, (size_t)T * F * sizeof(R)));
-    hipError_t e = hipMalloc((void**)&dout, (size_t)Tout * K * sizeof(R));
-    if (e != hipSuccess) { (void)hipFree(dx); return fail(ctx, HSCMP_ERR_ALLOC, "hscmp_convolve1d: %s", hipGetErrorString(e)); }
-    int rc = HSCMP_OK;
-    do {
-        if ((e = hipMemcpyAsync(dx, x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        DevParams P{};
-        P.B = 1; P.T = T; P.K = K; P.W = W; P.F = F; P.off = (W - 1) / 2;
-        State<R> S{};
-        S.D = (const R*)ctx->d_D; S.weights = nullptr;
-        S.Dc = ctx->d_Dc ? (const R*)ctx->d_Dc : (const R*)ctx->d_D;
-        dim3 grid((Tout + kThreads - 1) / kThreads, 1);
-        hipLaunchKernelGGL((corr_init_generic_kernel<R, true>), grid, dim3(kThreads), 0, ctx->stream, P, S, (const R*)dx,
-                           same ? P.off : 0, Tout, dout);
-        if ((e = hipGetLastError()) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(out, dout, (size_t)Tout * K * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-        e = hipStreamSynchronize(ctx->stream);
-    } while (0);
-    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_convolve1d: %s", hipGetErrorString(e));
-    (void)hipFree(dx); (void)hipFree(dout);
-    return rc;
+    int rc;
+    if ((rc = epi_buffer(ctx, kArenaRowA, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaRowB, (size_t)Tout * K * sizeof(R))) != HSCMP_OK) return rc;
+    R* dx = (R*)ctx->d_epi[kArenaRowA]; R* dout = (R*)ctx->d_epi[kArenaRowB];
+    HIP_TRY(ctx, hipMemcpyAsync(dx, x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    launch_convolve<R>(ctx, dx, T, same, Tout, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, (size_t)Tout * K * sizeof(R), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
 }
 
 extern "C" int hscmp_convolve1d(hscmp_ctx* ctx, const void* x, int T, int same, void* out)
@@ -873,27 +912,22 @@ static int run_assign(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t
 {
     const int K = ctx->K, W = ctx->W, F = ctx->F;
     const size_t wbytes = (size_t)N * L * F * sizeof(R);
-    R* dwin = nullptr; int* dt = nullptr; int* dk = nullptr; R* dc = nullptr;
-    hipError_t e = hipSuccess;
-    int rc = HSCMP_OK;
-    do {
-        if ((e = hipMalloc((void**)&dwin, wbytes)) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&dt, (size_t)N * sizeof(int))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&dk, (size_t)N * sizeof(int))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&dc, (size_t)N * sizeof(R))) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(dwin, windows, wbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        const int lds_elems = (size_t)L * F * sizeof(R) <= 32768 ? L * F : 0;
-        hipLaunchKernelGGL((assign_windows_kernel<R>), dim3(N), dim3(kThreads), (size_t)lds_elems * sizeof(R), ctx->stream,
-                           (const R*)dwin, L, K, W, F, (const R*)ctx->d_D, lds_elems, dt, dk, dc);
-        if ((e = hipGetLastError()) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(out_t, dt, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(out_k, dk, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-        if (out_c && (e = hipMemcpyAsync(out_c, dc, (size_t)N * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-        e = hipStreamSynchronize(ctx->stream);
-    } while (0);
-    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_assign_windows: %s", hipGetErrorString(e));
-    (void)hipFree(dwin); (void)hipFree(dt); (void)hipFree(dk); (void)hipFree(dc);
-    return rc;
+    int rc;
+    if ((rc = epi_buffer(ctx, kArenaRowA, wbytes)) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaRowB, (size_t)N * sizeof(int))) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaRowC, (size_t)N * sizeof(int))) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaRowD, (size_t)N * sizeof(R))) != HSCMP_OK) return rc;
+    R* dwin = (R*)ctx->d_epi[kArenaRowA]; int* dt = (int*)ctx->d_epi[kArenaRowB]; int* dk = (int*)ctx->d_epi[kArenaRowC]; R* dc = (R*)ctx->d_epi[kArenaRowD];
+    HIP_TRY(ctx, hipMemcpyAsync(dwin, windows, wbytes, hipMemcpyHostToDevice, ctx->stream));
+    const int lds_elems = (size_t)L * F * sizeof(R) <= 32768 ? L * F : 0;
+    hipLaunchKernelGGL((assign_windows_kernel<R>), dim3(N), dim3(kThreads), (size_t)lds_elems * sizeof(R), ctx->stream,
+                       (const R*)dwin, L, K, W, F, (const R*)ctx->d_D, lds_elems, dt, dk, dc);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_t, dt, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_k, dk, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_c) HIP_TRY(ctx, hipMemcpyAsync(out_c, dc, (size_t)N * sizeof(R), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
 }
 
 extern "C" int hscmp_assign_windows(hscmp_ctx* ctx, const void* windows, int N, int L, int32_t* out_t, int32_t* out_k, void* out_c)
@@ -978,16 +1012,6 @@ extern "C" int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slo
 }
 
 // ---- epilogue of the hierarchical encoder on the device (hscmp_epilogue.h) -----------------------------------------
-static int epi_buffer(hscmp_ctx* ctx, int i, size_t bytes)
-{
-    if (ctx->d_epi[i] && ctx->cap_epi[i] >= bytes) return HSCMP_OK;
-    if (ctx->d_epi[i]) { (void)hipFree(ctx->d_epi[i]); ctx->d_epi[i] = nullptr; ctx->cap_epi[i] = 0; }
-    const size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&ctx->d_epi[i], want);
-    if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-    ctx->cap_epi[i] = want;
-    return HSCMP_OK;
-}
 
 extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int first, const hscmp_epilogue_level* levels, int nlevels,
                                         double min_coefficients, const int64_t* offsets, int32_t* out_n, int32_t* out_colptr,
@@ -1097,62 +1121,70 @@ extern "C" int hscmp_debug_stamps(unsigned long long* out16, int reset)
 #endif
 
 // ---- row-level entry points (modeling.py:899-982 and :1018-1051) -------------------------------------
+// One selection (modeling.py:899-982) on a table that is ON THE DEVICE: d_ip [T][K], d_w [K] or null.  Uses the batch
+// workspace of the context (a batch held by the context is gone afterwards) but none of its dictionary state.
 template <typename R>
-static int run_select(hscmp_ctx* ctx, const void* ip, int T, int K, int W, int nb_blocks, int offset, double thres,
-                      const void* weights, int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out)
+static int select_on_device(hscmp_ctx* ctx, const R* d_ip, const R* d_w, int T, int K, int W, int nb_blocks, int offset, double thres,
+                            int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out, const char* who)
 {
     hscmp_params hp{};
     hp.nb_nonzero_coefs = -1; hp.nb_blocks = nb_blocks; hp.tolerance_snr = NAN; hp.tolerance_residual_scale = NAN;
     hp.null_coeff_thres = thres; hp.eps = 0.0; hp.max_events = 1; hp.max_rounds = 1;
-    // a throw-away geometry: only T, K, W matter for the selection
-    const int sK = ctx->K, sW = ctx->W, sF = ctx->F, sD = ctx->dtype;
-    ctx->K = K; ctx->W = W; ctx->F = 1; ctx->dtype = sizeof(R) == 8 ? HSCMP_F64 : HSCMP_F32;
     DevParams P;
-    int rc = make_params(ctx, 1, T, &hp, &P);
-    if (rc == HSCMP_OK) rc = ensure_workspace(ctx, P, false);
-    R* d_ip = nullptr; R* d_w = nullptr;
-    hipError_t e = hipSuccess;
-    if (rc == HSCMP_OK) {
-        do {
-            if ((e = hipMalloc((void**)&d_ip, (size_t)T * K * sizeof(R))) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(d_ip, ip, (size_t)T * K * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if (weights) {
-                if ((e = hipMalloc((void**)&d_w, (size_t)K * sizeof(R))) != hipSuccess) break;
-                if ((e = hipMemcpyAsync(d_w, weights, (size_t)K * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            }
-            State<R> S = make_state<R>(ctx);
-            S.D = nullptr; S.Dc = nullptr; S.weights = d_w;
-            hipLaunchKernelGGL((table_to_best_kernel<R>), dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
-                               (const R*)d_ip, T, K, (const R*)d_w, S.best_c, S.best_k);
-            int st[ST_COUNT] = {0};
-            st[ST_OFFSET] = offset ? 1 : 0;
-            if ((e = hipMemcpyAsync(ctx->d_stats, st, sizeof(st), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            P.select_only = 1; P.has_snr = 0; P.has_scale = 0;
-            set_segments(P, GenericRecorr<R>::kMaxSegments);
-            const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
-            auto kern = iterate_kernel<R, GenericRecorr<R>>;
-            if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) break;
-            hipLaunchKernelGGL(kern, dim3(1), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
-            if ((e = hipGetLastError()) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) break;
-            const int n = st[ST_EVENTS];
-            *n_out = n;
-            if (n > max_out) { rc = fail(ctx, HSCMP_ERR_INVALID, "hscmp_select_best_atoms: %d atoms selected, room for %d", n, max_out); break; }
-            if (n > 0) {
-                // the ordered list lives in the second half of the selection scratch
-                if ((e = hipMemcpy(out_t, ctx->d_sel_t + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
-                if ((e = hipMemcpy(out_k, ctx->d_sel_k + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
-                if ((e = hipMemcpy(out_c, (R*)ctx->d_sel_c + P.maxsel, (size_t)n * sizeof(R), hipMemcpyDeviceToHost)) != hipSuccess) break;
-            }
-        } while (0);
-        if (e != hipSuccess && rc == HSCMP_OK) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_select_best_atoms: %s", hipGetErrorString(e));
-    }
-    if (d_ip) (void)hipFree(d_ip);
-    if (d_w) (void)hipFree(d_w);
-    ctx->K = sK; ctx->W = sW; ctx->F = sF; ctx->dtype = sD;
+    int rc = make_params_g(ctx, K, W, 1, 1, T, &hp, &P);               // only T, K, W matter for the selection
+    if (rc == HSCMP_OK) rc = ensure_workspace_g(ctx, P, false, sizeof(R), false, false);
+    if (rc != HSCMP_OK) return rc;
     ctx->have_batch = false;
-    return rc;
+    State<R> S = make_state<R>(ctx);
+    S.D = nullptr; S.Dc = nullptr; S.weights = d_w;
+    hipLaunchKernelGGL((table_to_best_kernel<R>), dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
+                       d_ip, T, K, d_w, S.best_c, S.best_k);
+    int st[ST_COUNT] = {0};
+    st[ST_OFFSET] = offset ? 1 : 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stats, st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
+    P.select_only = 1; P.has_snr = 0; P.has_scale = 0;
+    set_segments(P, GenericRecorr<R>::kMaxSegments);
+    const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
+    auto kern = iterate_kernel<R, GenericRecorr<R>>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = st[ST_EVENTS];
+    *n_out = n;
+    if (n > max_out) return fail(ctx, HSCMP_ERR_INVALID, "%s: %d atoms selected, room for %d", who, n, max_out);
+    if (n > 0) {                                                        // the ordered list lives in the second half of the selection scratch
+        HIP_TRY(ctx, hipMemcpyAsync(out_t, ctx->d_sel_t + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_k, ctx->d_sel_k + P.maxsel, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_c, (R*)ctx->d_sel_c + P.maxsel, (size_t)n * sizeof(R), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return HSCMP_OK;
+}
+
+template <typename R> static int upload_weights(hscmp_ctx* ctx, const void* weights, int K, const R** d_w)
+{
+    *d_w = nullptr;
+    if (!weights) return HSCMP_OK;
+    int rc = epi_buffer(ctx, kArenaTabW, (size_t)K * sizeof(R));
+    if (rc != HSCMP_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaTabW], weights, (size_t)K * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    *d_w = (const R*)ctx->d_epi[kArenaTabW];
+    return HSCMP_OK;
+}
+
+template <typename R>
+static int run_select(hscmp_ctx* ctx, const void* ip, int T, int K, int W, int nb_blocks, int offset, double thres,
+                      const void* weights, int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out)
+{
+    int rc = epi_buffer(ctx, kArenaRowA, (size_t)T * K * sizeof(R));
+    if (rc != HSCMP_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaRowA], ip, (size_t)T * K * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    const R* d_w;
+    if ((rc = upload_weights<R>(ctx, weights, K, &d_w)) != HSCMP_OK) return rc;
+    return select_on_device<R>(ctx, (const R*)ctx->d_epi[kArenaRowA], d_w, T, K, W, nb_blocks, offset, thres, out_t, out_k, out_c, max_out, n_out,
+                               "hscmp_select_best_atoms");
 }
 
 extern "C" int hscmp_select_best_atoms(hscmp_ctx* ctx, const void* ip, int T, int K, int W, hscmp_dtype dtype, int nb_blocks,
@@ -1169,36 +1201,34 @@ extern "C" int hscmp_select_best_atoms(hscmp_ctx* ctx, const void* ip, int T, in
         : run_select<double>(ctx, ip, T, K, W, nb_blocks, offset, null_coeff_thres, weights, out_t, out_k, out_c, max_out, n_out);
 }
 
+template <typename R> static void launch_update_rows(hscmp_ctx* ctx, const R* d_r, int T, int p, R* d_rows, R* d_table)
+{
+    const int K = ctx->K, W = ctx->W, nrows = 2 * W - 1;
+    DevParams P{};
+    P.B = 1; P.T = T; P.K = K; P.W = W; P.F = ctx->F; P.off = (W - 1) / 2;
+    const int grid = (nrows * K + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL((update_rows_kernel<R>), dim3(grid), dim3(kThreads), 0, ctx->stream, P, d_r, (const R*)ctx->d_D, p, d_rows, d_table);
+}
+
 template <typename R> static int run_update_rows(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p)
 {
     const int K = ctx->K, W = ctx->W, F = ctx->F, nrows = 2 * W - 1;
-    R* d_r = nullptr; R* d_out = nullptr;
-    hipError_t e;
-    int rc = HSCMP_OK;
+    int rc;
+    if ((rc = epi_buffer(ctx, kArenaRowA, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaRowB, (size_t)nrows * K * sizeof(R))) != HSCMP_OK) return rc;
+    R* d_r = (R*)ctx->d_epi[kArenaRowA]; R* d_out = (R*)ctx->d_epi[kArenaRowB];
     std::vector<R> rows((size_t)nrows * K);
-    do {
-        if ((e = hipMalloc((void**)&d_r, (size_t)T * F * sizeof(R))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&d_out, (size_t)nrows * K * sizeof(R))) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(d_r, residual, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        DevParams P{};
-        P.B = 1; P.T = T; P.K = K; P.W = W; P.F = F; P.off = (W - 1) / 2;
-        const int grid = (nrows * K + kThreads - 1) / kThreads;
-        hipLaunchKernelGGL((update_rows_kernel<R>), dim3(grid), dim3(kThreads), 0, ctx->stream, P, (const R*)d_r, (const R*)ctx->d_D, p, d_out);
-        if ((e = hipGetLastError()) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(rows.data(), d_out, rows.size() * sizeof(R), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-        e = hipStreamSynchronize(ctx->stream);
-    } while (0);
-    if (e != hipSuccess) rc = fail(ctx, HSCMP_ERR_HIP, "hscmp_update_inner_products: %s", hipGetErrorString(e));
-    if (rc == HSCMP_OK) {
-        R* tab = (R*)ip;
-        for (int row = 0; row < nrows; ++row) {               // overlapReplace clipping (utils.py:133-161)
-            const int t = p - (W - 1) + row;
-            if (t >= 0 && t < T) memcpy(tab + (size_t)t * K, rows.data() + (size_t)row * K, (size_t)K * sizeof(R));
-        }
+    HIP_TRY(ctx, hipMemcpyAsync(d_r, residual, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    launch_update_rows<R>(ctx, d_r, T, p, d_out, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_out, rows.size() * sizeof(R), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    R* tab = (R*)ip;
+    for (int row = 0; row < nrows; ++row) {               // overlapReplace clipping (utils.py:133-161)
+        const int t = p - (W - 1) + row;
+        if (t >= 0 && t < T) memcpy(tab + (size_t)t * K, rows.data() + (size_t)row * K, (size_t)K * sizeof(R));
     }
-    if (d_r) (void)hipFree(d_r);
-    if (d_out) (void)hipFree(d_out);
-    return rc;
+    return HSCMP_OK;
 }
 
 extern "C" int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p)
@@ -1209,4 +1239,87 @@ extern "C" int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void*
     if (p < 0 || p >= T) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_update_inner_products: atom centre %d outside the signal [0, %d)", p, T);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ctx->dtype == HSCMP_F32 ? run_update_rows<float>(ctx, ip, residual, T, p) : run_update_rows<double>(ctx, ip, residual, T, p);
+}
+
+// ---- LoCOMP's table on the device (hsc/modeling.py:1267-1425) -----------------------------------------------------------
+// The reference keeps innerProducts[T][K] and the residual as host arrays and edits both around every selected atom.
+// Here both live in the context's arena: open = :1293 (innerProducts = convolve1d(residual, D, 'same')), select =
+// _selectBestAtoms (:899-982) on the resident table, update = the caller's new residual samples + _updateInnerProducts
+// (:1018-1051) for every atom of the re-fitted group, in place.  Per iteration the host moves O(W) samples, not T*K.
+template <typename R> static int run_table_open(hscmp_ctx* ctx, const void* x, int T)
+{
+    const int K = ctx->K, F = ctx->F;
+    int rc;
+    if ((rc = epi_buffer(ctx, kArenaTabRes, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
+    if ((rc = epi_buffer(ctx, kArenaTable, (size_t)T * K * sizeof(R))) != HSCMP_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaTabRes], x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    launch_convolve<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 1, T, (R*)ctx->d_epi[kArenaTable]);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->tab_T = T;
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_table_open(hscmp_ctx* ctx, const void* x, int T)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_table_open: ctx is NULL");
+    if (ctx->dtype < 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_table_open: no dictionary set");
+    if (!x || T <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_table_open: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->tab_T = 0;
+    return ctx->dtype == HSCMP_F32 ? run_table_open<float>(ctx, x, T) : run_table_open<double>(ctx, x, T);
+}
+
+extern "C" int hscmp_table_select(hscmp_ctx* ctx, int nb_blocks, int offset, double null_coeff_thres, const void* weights,
+                                  int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_table_select: ctx is NULL");
+    if (ctx->tab_T <= 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_table_select: no table open (hscmp_table_open)");
+    if (!out_t || !out_k || !out_c || !n_out) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_table_select: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (ctx->dtype == HSCMP_F32) {
+        const float* d_w;
+        if ((rc = upload_weights<float>(ctx, weights, ctx->K, &d_w)) != HSCMP_OK) return rc;
+        return select_on_device<float>(ctx, (const float*)ctx->d_epi[kArenaTable], d_w, ctx->tab_T, ctx->K, ctx->W, nb_blocks, offset, null_coeff_thres,
+                                       out_t, out_k, out_c, max_out, n_out, "hscmp_table_select");
+    }
+    const double* d_w;
+    if ((rc = upload_weights<double>(ctx, weights, ctx->K, &d_w)) != HSCMP_OK) return rc;
+    return select_on_device<double>(ctx, (const double*)ctx->d_epi[kArenaTable], d_w, ctx->tab_T, ctx->K, ctx->W, nb_blocks, offset, null_coeff_thres,
+                                    out_t, out_k, out_c, max_out, n_out, "hscmp_table_select");
+}
+
+extern "C" int hscmp_table_update(hscmp_ctx* ctx, const void* residual_samples, int start, int count, const int32_t* centres, int ncentres)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_table_update: ctx is NULL");
+    if (ctx->tab_T <= 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_table_update: no table open (hscmp_table_open)");
+    const int T = ctx->tab_T;
+    if (count < 0 || start < 0 || start + count > T || (count > 0 && !residual_samples) || ncentres < 0 || (ncentres > 0 && !centres))
+        return fail(ctx, HSCMP_ERR_INVALID, "hscmp_table_update: bad arguments (start=%d count=%d T=%d)", start, count, T);
+    for (int i = 0; i < ncentres; ++i)
+        if (centres[i] < 0 || centres[i] >= T) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_table_update: atom centre %d outside the signal [0, %d)", centres[i], T);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t es = esize(ctx->dtype), row = (size_t)ctx->F * es;
+    if (count > 0)
+        HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->d_epi[kArenaTabRes] + (size_t)start * row, residual_samples, (size_t)count * row, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < ncentres; ++i) {
+        if (ctx->dtype == HSCMP_F32) launch_update_rows<float>(ctx, (const float*)ctx->d_epi[kArenaTabRes], T, centres[i], nullptr, (float*)ctx->d_epi[kArenaTable]);
+        else launch_update_rows<double>(ctx, (const double*)ctx->d_epi[kArenaTabRes], T, centres[i], nullptr, (double*)ctx->d_epi[kArenaTable]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // the host buffer may be reused as soon as this returns
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
+extern "C" int hscmp_table_read(hscmp_ctx* ctx, void* out_table, void* out_residual)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_table_read: ctx is NULL");
+    if (ctx->tab_T <= 0) return fail(ctx, HSCMP_ERR_STATE, "hscmp_table_read: no table open (hscmp_table_open)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t es = esize(ctx->dtype);
+    if (out_table) HIP_TRY(ctx, hipMemcpyAsync(out_table, ctx->d_epi[kArenaTable], (size_t)ctx->tab_T * ctx->K * es, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_residual) HIP_TRY(ctx, hipMemcpyAsync(out_residual, ctx->d_epi[kArenaTabRes], (size_t)ctx->tab_T * ctx->F * es, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
 }

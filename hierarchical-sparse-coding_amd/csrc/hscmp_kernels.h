@@ -305,10 +305,11 @@ __global__ __launch_bounds__(kThreads) void table_to_best_kernel(const R* __rest
 }
 
 // rows p-(W-1) .. p+(W-1) of the inner-product table from the reflect-padded residual span
-// (modeling.py:1018-1051, entry point of _updateInnerProducts): out[(2W-1)][K]
+// (modeling.py:1018-1051, entry point of _updateInnerProducts): out[(2W-1)][K], or -- `table` given -- straight into the
+// rows of a device-resident table [T][K] with the clipping of overlapReplace (utils.py:133-161)
 template <typename R>
 __global__ __launch_bounds__(kThreads) void update_rows_kernel(DevParams P, const R* __restrict__ r, const R* __restrict__ D, int p,
-                                                               R* __restrict__ out)
+                                                               R* __restrict__ out, R* __restrict__ table)
 {
     const int T = P.T, K = P.K, W = P.W, F = P.F;
     const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(kThreads) void update_rows_kernel(DevParams P, cons
                 const int g = reflect_index(t - P.off + w, sidx, nslice);
                 acc = rfma(r[(int64_t)g * F + f], dk[w * F + f], acc);
             }
-        out[o] = acc;
+        if (table) { if (t >= 0 && t < T) table[(int64_t)t * K + k] = acc; }
+        else out[o] = acc;
     }
 }
 

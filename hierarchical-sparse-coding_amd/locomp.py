@@ -6,19 +6,22 @@ Same outer loop as the greedy coder, but after each selection the coefficients o
 selected atoms whose support overlaps the new one are re-fitted jointly (least squares on the local
 residual), then the residual and the inner products are updated for every atom of that group.
 
-The heavy operations run on the GPU through the same C ABI as the greedy coder -- initial correlation
-(hscmp_convolve1d), selection (hscmp_select_best_atoms), local re-correlation
-(hscmp_update_inner_products); the loop itself and the tiny least-squares systems (a handful of atoms
-by ~3W samples, np.linalg.pinv as in the reference, :1326) are host side.  The materialised table
-travels with every selection call, so this coder targets the reference's use of LoCOMP (moderate T);
-the table-free persistent-kernel engine is ConvolutionalMatchingPursuit.
+The heavy operations run on the GPU through the same C ABI as the greedy coder.  The materialised table
+`innerProducts` [T, K] and a copy of the residual live ON THE DEVICE for the whole encode (hscmp_table_open =
+the initial correlation, hscmp_table_select = the selection, hscmp_table_update = local re-correlation in
+place): per iteration the host sends the ~3W residual samples a re-fitted group changed and receives the
+selected atoms.  The loop itself and the tiny least-squares systems (a handful of atoms by ~3W samples,
+np.linalg.pinv as in the reference, :1326) are host side.  The table-free persistent-kernel engine is
+ConvolutionalMatchingPursuit.
 """
+import bisect
 import logging
 
 import numpy as np
 import scipy.sparse
 
-from .modeling import Atom, ConvolutionalMatchingPursuit, _compute_dtype, convolve1d
+from . import _native
+from .modeling import Atom, ConvolutionalMatchingPursuit, _compute_dtype
 from .utils import overlapAdd, peek
 
 logger = logging.getLogger(__name__)
@@ -29,6 +32,14 @@ class LoCOMP(ConvolutionalMatchingPursuit):
     def __init__(self, verbose=False, device=0):
         super(LoCOMP, self).__init__(verbose, device)
 
+    def _initialInnerProducts(self, residual, D, dt):
+        """:1293 innerProducts = convolve1d(residual, D, padding='same') -- computed and KEPT on the device
+        (hscmp_table_open): _selectBestAtoms reads it there, _updateInnerProducts edits it there.  Returns the handle
+        (_native.DeviceTable) the two hooks understand."""
+        eng = _native.default_engine(self.device)
+        eng.set_dictionary(np.asarray(D, dtype=dt))
+        return eng.table_open(np.asarray(residual, dtype=dt))
+
     def _findCommonSupportAtoms(self, atom, coefficients, D):
         """Previously selected atoms in the neighbourhood of `atom` (:1222-1241).  As in the reference
         the exclusion test compares the window-relative row with the absolute position, and drops
@@ -37,9 +48,38 @@ class LoCOMP(ConvolutionalMatchingPursuit):
         start, end = atom.getPositionSpanIndices(T)
         start = max(start - W // 2, 0)
         end = min(end + (W // 2 - 1 if W % 2 == 0 else W // 2), T)
+        index = getattr(self, '_support', None)
+        if index is not None and index[0] is coefficients:
+            # the encode loop keeps the non-zero entries by position next to the matrix: same entries, same order
+            # (rows ascending, columns ascending) as slicing the T x K list-of-lists matrix, without building one
+            _, positions, entries = index
+            out = []
+            for q in range(bisect.bisect_left(positions, start), bisect.bisect_right(positions, end)):
+                t = positions[q]
+                for k in sorted(entries[t]):
+                    if (t - start) != atom.position and k != atom.index:
+                        out.append(Atom(t, k, entries[t][k], W))
+            return out
         sub = coefficients[start:end + 1, :].tocoo()
         return [Atom(start + int(r), int(k), c, W) for r, k, c in zip(sub.row, sub.col, sub.data)
                 if r != atom.position and k != atom.index]
+
+    def _track(self, coefficients, atoms):
+        """Mirror of the matrix entries the atoms touched (a list-of-lists matrix drops an entry that became 0.0)."""
+        _, positions, entries = self._support
+        for a in atoms:
+            v = coefficients[a.position, a.index]
+            row = entries.get(a.position)
+            if v != 0.0:
+                if row is None:
+                    row = entries[a.position] = {}
+                    bisect.insort(positions, a.position)
+                row[a.index] = v
+            elif row is not None and a.index in row:
+                del row[a.index]
+                if not row:
+                    del entries[a.position]
+                    positions.pop(bisect.bisect_left(positions, a.position))
 
     def _getDictionaryFromSupportAtoms(self, sequence, atoms, D):
         """Local dictionary of the group: every atom placed on the union of the supports (:1243-1265)."""
@@ -69,7 +109,8 @@ class LoCOMP(ConvolutionalMatchingPursuit):
         residual = np.copy(sequence)
         energyResidual = energySignal
         coefficients = scipy.sparse.lil_matrix((sequence.shape[0], D.shape[0]))
-        innerProducts = np.ascontiguousarray(convolve1d(residual, D, padding='same', device=self.device), dtype=dt)   # :1293
+        self._support = (coefficients, [], {})
+        innerProducts = self._initialInnerProducts(residual, D, dt)                                                   # :1293
 
         offset = False
         converged = False
@@ -96,6 +137,7 @@ class LoCOMP(ConvolutionalMatchingPursuit):
                 else:
                     group = [atom]
                 coefficients = self._updateCoefficients(coefficients, group, replace=False)
+                self._track(coefficients, group)
                 residual, energyResidual = self._updateResidual(residual, energyResidual, group, D, eps)
                 innerProducts = self._updateInnerProducts(innerProducts, residual, group, D)
 
@@ -123,6 +165,7 @@ class LoCOMP(ConvolutionalMatchingPursuit):
                 converged = True
             offset = not offset
 
+        self._support = None
         if minCoefficients is not None:                                           # :1411-1417
             cx = coefficients.tocoo()
             keep = np.abs(cx.data) >= minCoefficients

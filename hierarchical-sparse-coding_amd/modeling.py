@@ -207,6 +207,9 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         """hsc/modeling.py:899-982 on a materialised table [T,K]; returns the reference's list of Atom."""
         if weights is not None:
             assert len(weights) == innerProducts.shape[1]
+        if isinstance(innerProducts, _native.DeviceTable):          # the table lives on the device: nothing to upload
+            t, k, c = innerProducts.engine.table_select(nbBlocks, offset, nullCoeffThres, weights)
+            return [Atom(int(p), int(f), cc, filterWidth) for p, f, cc in zip(t, k, c)]
         dt = _compute_dtype(innerProducts.dtype)
         eng = _native.default_engine(self.device)
         t, k, c = eng.select_best_atoms(np.asarray(innerProducts, dtype=dt), filterWidth, nbBlocks, offset, nullCoeffThres,
@@ -238,6 +241,13 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
 
     def _updateInnerProducts(self, innerProducts, residual, atoms, D):
         """hsc/modeling.py:1018-1051: rows p-(W-1)..p+(W-1) re-correlated on the GPU, in place."""
+        if isinstance(innerProducts, _native.DeviceTable):
+            # device-resident table: hand over the residual samples the atoms changed (the union of their supports),
+            # the rows around every atom are recomputed where the table lives
+            spans = [centered_span(residual.shape[0], a.length, a.position)[:2] for a in atoms]
+            lo, hi = min(s for s, _ in spans), max(e for _, e in spans)
+            innerProducts.engine.table_update(residual[lo:hi], lo, [a.position for a in atoms])
+            return innerProducts
         dt = _compute_dtype(innerProducts.dtype, D.dtype)
         if innerProducts.dtype != dt or not innerProducts.flags.c_contiguous:
             raise TypeError('innerProducts must be a C-contiguous %s array' % dt)

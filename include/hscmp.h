@@ -116,6 +116,24 @@ int hscmp_select_best_atoms(hscmp_ctx* ctx, const void* ip, int T, int K, int W,
  * context's dictionary and replaces them in ip [T][K] (host, in place). */
 int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void* residual, int T, int p);
 
+/* LoCOMP (modeling.py:1267-1425) keeps `innerProducts` [T][K] and the residual as arrays that it edits around every
+ * selected atom.  These four entry points keep both ON THE DEVICE, inside the context, so that an iteration moves
+ * O(W) samples over PCIe instead of the T*K table:
+ *   hscmp_table_open    innerProducts = convolve1d(x, D, padding='same') (:1293); residual := x [T][F] (host, dtype)
+ *   hscmp_table_select  _selectBestAtoms (:899-982) on the resident table; arguments as hscmp_select_best_atoms
+ *   hscmp_table_update  the residual samples [start, start+count) are replaced by residual_samples [count][F] (host;
+ *                       what _updateResidual :996-1016 produced for the re-fitted group), then _updateInnerProducts
+ *                       (:1018-1051) runs in place for every atom centre of centres[ncentres]
+ *   hscmp_table_read    copies the table [T][K] and / or the residual [T][F] back (either may be NULL): tests, and
+ *                       callers that want the reference's arrays
+ * The table belongs to the context's dictionary and stays valid until the next hscmp_table_open, hscmp_set_dictionary
+ * or hscmp_destroy; selecting on it reuses the batch workspace (a batch held by the context is dropped). */
+int hscmp_table_open(hscmp_ctx* ctx, const void* x, int T);
+int hscmp_table_select(hscmp_ctx* ctx, int nb_blocks, int offset, double null_coeff_thres, const void* weights,
+                       int32_t* out_t, int32_t* out_k, void* out_c, int max_out, int32_t* n_out);
+int hscmp_table_update(hscmp_ctx* ctx, const void* residual_samples, int start, int count, const int32_t* centres, int ncentres);
+int hscmp_table_read(hscmp_ctx* ctx, void* out_table, void* out_residual);
+
 /* ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053-1169) for a batch of B
  * independent signals x [B][T][F] (host memory): initial correlation, then the greedy
  * select / subtract / local re-correlate loop, entirely on the GPU.  Results stay in the

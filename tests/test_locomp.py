@@ -56,16 +56,18 @@ class _OracleHooks(object):
             orc.update_inner_products(innerProducts, residual, D, a.position)
         return innerProducts
 
+    def _initialInnerProducts(self, residual, D, dt):
+        from oracle import hsc_oracle as orc
+        return np.ascontiguousarray(orc.convolve1d(residual, D, padding='same'), dtype=dt)
+
 
 @pytest.mark.parametrize('name', _names())
-def test_locomp_host_loop_with_oracle_hooks(name, monkeypatch):
-    from oracle import hsc_oracle as orc
+def test_locomp_host_loop_with_oracle_hooks(name):
     import hsc_amd.locomp as locomp
 
     class OracleLoCOMP(_OracleHooks, locomp.LoCOMP):
         pass
 
-    monkeypatch.setattr(locomp, 'convolve1d', lambda seq, D, padding='valid', device=0: orc.convolve1d(seq, D, padding=padding))
     _check(OracleLoCOMP(), name)
 
 
@@ -93,3 +95,60 @@ def test_hierarchical_default_method_is_locomp():
         assert np.array_equal(row, z['case_d__level%d_row' % l]) and np.array_equal(col, z['case_d__level%d_col' % l])
         assert float(np.max(np.abs(data - z['case_d__level%d_data' % l]))) <= 2e-4
     assert float(np.max(np.abs(residual - z['case_d__residual']))) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_device_resident_table_equals_host_table_ops(dtype):
+    """hscmp_table_open / _select / _update (the table and the residual stay on the device) against the oracle's
+    operations on a host table, bit for bit: initial table, four rounds of select + residual edit + in-place update
+    (atoms at the signal ends and inside), blocked and single selection, with and without weights."""
+    from oracle import hsc_oracle as orc
+    from hsc_amd import _native
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit, Atom
+    rs = np.random.RandomState(11)
+    T, K, W = 700, 24, 17
+    D = rs.standard_normal((K, W, 1)).astype(dtype)
+    D /= np.sqrt(np.sum(D ** 2, axis=(1, 2), keepdims=True))
+    x = rs.standard_normal((T, 1)).astype(dtype)
+    eng = _native.default_engine(0)
+    eng.set_dictionary(D)
+    tab = eng.table_open(x)
+    ip = np.ascontiguousarray(orc.convolve1d(x, D, padding='same'), dtype=dtype)
+    assert np.array_equal(tab.read(), ip)
+    cmp = ConvolutionalMatchingPursuit()
+    residual = x.copy()
+    weights = (0.5 + rs.rand(K)).astype(dtype)
+    for rnd, (nb, w, offs) in enumerate([(1, None, False), (5, None, True), ('auto', weights, False), (3, weights, True)]):
+        got = cmp._selectBestAtoms(tab, W, nbBlocks=nb, offset=offs, nullCoeffThres=1e-6, weights=w)
+        t, k, c = orc.select_best_atoms(ip, W, nb, offs, 1e-6, w)
+        assert [a.position for a in got] == [int(v) for v in t] and [a.index for a in got] == [int(v) for v in k]
+        assert np.array_equal(np.array([a.coefficient for a in got], dtype=dtype), c)
+        atoms = got[:3] + [Atom(0, 1, 0.25, W), Atom(T - 1, 2, -0.5, W), Atom(W, 3, 0.125, W)]
+        residual, _ = cmp._updateResidual(residual, 0.0, atoms, D)
+        cmp._updateInnerProducts(tab, residual, atoms, D)
+        for a in atoms:
+            orc.update_inner_products(ip, residual, D, a.position)
+        tb, rb = eng.table_read(table=True, residual=True)
+        assert np.array_equal(tb, ip), rnd
+        assert np.array_equal(rb, residual), rnd
+
+
+@pytest.mark.gpu
+def test_table_calls_without_open_table_fail_loudly():
+    from hsc_amd import _native
+    eng = _native.Engine(0)
+    D = np.eye(4, 5, dtype=np.float32)[:, :, None]
+    eng.set_dictionary(D)
+    eng._table_T = 16
+    with pytest.raises(_native.HscmpError):
+        eng.table_select()
+    tab = eng.table_open(np.zeros((16, 1), dtype=np.float32))
+    with pytest.raises(_native.HscmpError):
+        eng.table_update(np.zeros((4, 1), dtype=np.float32), 14, [3])       # samples past the end
+    with pytest.raises(_native.HscmpError):
+        eng.table_update(np.zeros((4, 1), dtype=np.float32), 0, [16])       # centre outside the signal
+    eng.set_dictionary(2 * D)                                               # a new dictionary drops the table
+    with pytest.raises(_native.HscmpError):
+        tab.read()
+    eng.close()
