@@ -45,6 +45,11 @@ struct hscmp_ctx {
     int* d_rl_cnt = nullptr;  // per-row feature lists of the residual's possibly non-zero cells (sparse dictionaries)
     int* d_rl_f = nullptr;
     bool rl_filled = false;   // the lists of the current input were written by the level chaining
+    // rows of d_resid (x F float64) that a chained encode left behind with every possibly non-zero cell named by
+    // d_rl_cnt / d_rl_f: the next chained encode clears those cells instead of the whole buffer (0: clear everything)
+    int64_t listed_rows = 0;
+    int listed_F = 0;
+    bool loop_kept_lists = false;   // the last encode ran the sparse loop with row lists (it enters every cell it writes)
     unsigned char* d_rowflag = nullptr;  // [B][T] non-zero input rows handed over by the level chaining
     bool rowflag_valid = false;
     size_t Dfrag_bytes = 0;
@@ -189,7 +194,7 @@ extern "C" int hscmp_synchronize(hscmp_ctx* ctx)
 
 extern "C" int hscmp_set_dictionary(hscmp_ctx* ctx, const void* D, int K, int W, int F, hscmp_dtype dtype, const void* weights)
 {
-    if (ctx) ctx->tab_T = 0;                               // a resident table belongs to the dictionary it was built with
+    if (ctx) { ctx->tab_T = 0; ctx->listed_rows = 0; }     // a resident table belongs to the dictionary it was built with
     if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_set_dictionary: ctx is NULL");
     if (!D || K <= 0 || W <= 0 || F <= 0) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad shape K=%d W=%d F=%d", K, W, F);
     if (dtype != HSCMP_F32 && dtype != HSCMP_F64) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_dictionary: bad dtype %d", (int)dtype);
@@ -406,6 +411,7 @@ static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, s
         if (b.bytes == 0 || (*b.p && *b.cap >= b.bytes)) continue;
         if (!stream_idle) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); stream_idle = true; }
         if (*b.p) { (void)hipFree(*b.p); *b.p = nullptr; *b.cap = 0; }
+        ctx->listed_rows = 0;                   // (a fresh buffer knows nothing of the previous batch)
         hipError_t e = hipMalloc(b.p, b.bytes);
         if (e != hipSuccess) return fail(ctx, HSCMP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", b.bytes, hipGetErrorString(e));
         *b.cap = b.bytes;
@@ -579,6 +585,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
         mfi = true;
     }
     const bool spl = !mfi && use_sparse_loop(ctx);
+    ctx->loop_kept_lists = spl && use_row_lists(ctx);
     if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
     else if (!mfi) { int rc = launch_iterate<R>(ctx, P); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -605,6 +612,7 @@ static int encode_common(hscmp_ctx* ctx, const void* x, bool host, int B, int T,
         xd = ctx->d_x;
     }
     ctx->P = P; ctx->last = *params; ctx->B = B; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
+    ctx->listed_rows = 0;                       // the residual buffer is overwritten with a dense input
     ctx->last_x_dev = xd;
     rc = ctx->dtype == HSCMP_F32 ? run_encode<float>(ctx, P, xd) : run_encode<double>(ctx, P, xd);
     if (rc) return rc;
@@ -640,9 +648,18 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     if (rc) return rc;
     if ((rc = ensure_workspace(ctx, P, false))) return rc;        // no input buffer: the slots are scattered straight into the residual
     const size_t bytes = (size_t)count * T * ctx->F * sizeof(double);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_resid, 0, bytes, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rowflag, 0, (size_t)count * T, ctx->stream));
     const bool lists = use_sparse_loop(ctx) && use_row_lists(ctx);
+    if (ctx->listed_rows > 0 && ctx->listed_F == ctx->F && !getenv("HSCMP_NO_LAZY_CLEAR")) {
+        // the buffer still holds the previous chained batch; its lists say where
+        hipLaunchKernelGGL((clear_listed_cells_kernel<double>), dim3((unsigned)((ctx->listed_rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                           (double*)ctx->d_resid, ctx->listed_rows, ctx->F, ctx->d_rl_cnt, ctx->d_rl_f, kRowListCap);
+        const size_t covered = (size_t)ctx->listed_rows * ctx->F * sizeof(double);
+        if (bytes > covered) HIP_TRY(ctx, hipMemsetAsync((char*)ctx->d_resid + covered, 0, bytes - covered, ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_resid, 0, bytes, ctx->stream));
+    }
+    ctx->listed_rows = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rowflag, 0, (size_t)count * T, ctx->stream));
     if (lists) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_cnt, 0, (size_t)count * T * sizeof(int), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_rl_f, 0xff, (size_t)count * T * kRowListCap * sizeof(int), ctx->stream));
@@ -661,6 +678,8 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     if (rc) return rc;
     ctx->have_batch = true;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (only now: a failed launch leaves the buffer in an unknown state, and so does any other writer -- see the resets)
+    if (lists && ctx->loop_kept_lists) { ctx->listed_rows = (int64_t)count * T; ctx->listed_F = ctx->F; }
     return HSCMP_OK;
 }
 
@@ -1135,6 +1154,7 @@ static int select_on_device(hscmp_ctx* ctx, const R* d_ip, const R* d_w, int T, 
     if (rc == HSCMP_OK) rc = ensure_workspace_g(ctx, P, false, sizeof(R), false, false);
     if (rc != HSCMP_OK) return rc;
     ctx->have_batch = false;
+    ctx->listed_rows = 0;
     State<R> S = make_state<R>(ctx);
     S.D = nullptr; S.Dc = nullptr; S.weights = d_w;
     hipLaunchKernelGGL((table_to_best_kernel<R>), dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,

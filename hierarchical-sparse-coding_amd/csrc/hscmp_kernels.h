@@ -266,6 +266,26 @@ __global__ __launch_bounds__(kThreads) void scatter_slots_kernel(R* __restrict__
     }
 }
 
+// Zero the cells of x [rows][F] that the row lists name (a row whose list overflowed: all of it).  After an encode
+// whose loop kept the lists current these are the only cells of the dense level input / residual that can be
+// non-zero, so the next batch's "zero filled" buffer costs a pass over the list counters instead of a memset of
+// rows x F values (config 4, 1024 signals: 137 GB).    grid = ceil(rows / kThreads)
+template <typename R>
+__global__ __launch_bounds__(kThreads) void clear_listed_cells_kernel(R* __restrict__ x, int64_t rows, int F, const int* __restrict__ rl_cnt,
+                                                                      const int* __restrict__ rl_f, int rl_cap)
+{
+    const int64_t row = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (row >= rows) return;
+    const int n = rl_cnt[row];
+    if (n <= 0) return;
+    R* xr = x + row * F;
+    if (n > rl_cap) { for (int f = 0; f < F; ++f) xr[f] = (R)0; return; }
+    for (int i = 0; i < n; ++i) {
+        const int f = rl_f[row * rl_cap + i];
+        if (f >= 0 && f < F) xr[f] = (R)0;
+    }
+}
+
 // Per-row feature lists of a dense multi-feature input x [B][T][F]: rl_cnt[b][t] = number of non-zero
 // features of row t (may exceed rl_cap: the row is then treated as dense), rl_f[b][t][0..rl_cap) their
 // indices in any order (-1 = empty; both arrays must be pre-filled with 0 / -1).

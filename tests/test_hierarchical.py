@@ -284,3 +284,44 @@ def test_device_epilogue_equals_host_epilogue(distributed):
             assert ed[b].dtype == eh[b].dtype and np.array_equal(ed[b], eh[b]), b
             assert np.array_equal(ed[b], convertSparseMatricesToEvents(cd[b]))
     hcmp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['config4_dims', 'three_levels_dense_rows'])
+def test_level_input_buffer_is_clean_for_the_next_batch(case, monkeypatch):
+    """Levels >= 1 read a dense [T, F] buffer that holds the previous level's coefficients.  Between batches the
+    engine zeroes only the cells its row lists name (hscmp_api.hip: clear_listed_cells_kernel) instead of the whole
+    buffer: batch A, then a DIFFERENT batch B through the same coder must equal B through a fresh coder that clears
+    everything (HSCMP_NO_LAZY_CLEAR), bit for bit -- including inputs with rows that overflow their lists."""
+    import hsc_amd.synth as synth
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    if case == 'config4_dims':
+        mld = synth.make_hierarchy(W1=17, seed=4)
+        mlds = mld.withSingletonBases()
+        T, B = 8192, 24
+        xa = synth.make_hierarchy_batch(mld, T, 0, B, seed=4)
+        xb = synth.make_hierarchy_batch(mld, T, 1000, B, seed=9)
+        kw = dict(toleranceSnr=[30.0, 30.0], nbBlocks=10, singletonWeight=0.9)
+    else:
+        z = _golden()
+        mlds = _mld().withSingletonBases()
+        rs = np.random.RandomState(3)
+        base = z['x']
+        xa = np.stack([base, base[::-1].copy(), np.roll(base, 11)]).astype(np.float32)
+        # noise: level-0 codes with many atoms per position => level-1 rows with more cells than a row list holds
+        xb = (0.5 * rs.standard_normal(xa.shape)).astype(np.float32)
+        kw = dict(toleranceSnr=[12.0, 14.0, 14.0], nbBlocks=4, singletonWeight=0.9)
+    warm = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    warm.computeCoefficientsBatch(xa, mlds, **kw)
+    cb, rb, _ = warm.computeCoefficientsBatch(xb, mlds, **kw)
+    ca, ra, _ = warm.computeCoefficientsBatch(xa[:2], mlds, **kw)          # and a smaller batch after a larger one
+    monkeypatch.setenv('HSCMP_NO_LAZY_CLEAR', '1')
+    fresh = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    cb2, rb2, _ = fresh.computeCoefficientsBatch(xb, mlds, **kw)
+    ca2, ra2, _ = fresh.computeCoefficientsBatch(xa[:2], mlds, **kw)
+    assert np.array_equal(rb, rb2) and np.array_equal(ra, ra2)
+    for got, exp in ((cb, cb2), (ca, ca2)):
+        for b in range(len(exp)):
+            for l in range(len(exp[b])):
+                assert (scipy.sparse.csc_matrix(got[b][l]) != scipy.sparse.csc_matrix(exp[b][l])).nnz == 0, (b, l)
+    warm.close(); fresh.close()
