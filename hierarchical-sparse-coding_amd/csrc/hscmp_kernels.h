@@ -832,6 +832,9 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     const double thres = P.thres;
     const bool has_thres = P.has_thres != 0;
 
+    // several signals per workgroup: a signal's serial code outranks the other signals' tiles (hscmp_mfma.h, apply_atom)
+    if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
+
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         int nsel;

@@ -252,6 +252,11 @@ __device__ __forceinline__ float mfma_tile_score_lean(const float* __restrict__ 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
             a = an;
+#ifndef HSCMP_LEAN_NO_SCHED_BARRIER
+            // nothing moves across a chunk boundary: left alone the scheduler hoists the operand reads of several chunks
+            // ahead (the tile then wants 145 VGPRs by itself and the kernel around it spills)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
     auto reduce_all = [&](const f32x16& acc, int g) {
@@ -695,8 +700,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     }
     static __device__ __forceinline__ int signal_lds_offset(const DevParams& P, const Args& A)
     {
+        // (readfirstlane: the sizes involve an integer division, which the compiler carries out on the vector ALU -- the
+        // uniform result would sit in a VGPR, and with it every LDS address derived from it, live across the whole loop)
         if constexpr (GS == 1) return 0;
-        else return (int)(shared_lds_bytes(A) + (size_t)gsig() * per_signal_lds_bytes(P, A));
+        else return __builtin_amdgcn_readfirstlane((int)shared_lds_bytes(A) + gsig() * (int)per_signal_lds_bytes(P, A));
     }
     static __device__ __forceinline__ Layout layout(const DevParams& P, const Args& A, char* lds)
     {
@@ -706,7 +713,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         L.wts = L.dimg + A.G * S4 * Tile::kChunkElems;
         L.nwin = window_floats(P.W, S4);
         L.wp = 8 * S4;
-        L.nsbmax = segbuf_len(P.W, P.seg);
+        L.nsbmax = __builtin_amdgcn_readfirstlane(segbuf_len(P.W, P.seg));      // (integer division: see signal_lds_offset)
         L.win = GS == 1 ? L.wts + (HAS_W ? Tile::GA * A.G : 0) : reinterpret_cast<R*>(lds);
         L.esq = L.win + L.nwin;
         L.sbs = L.esq + 2 * L.wp;
@@ -808,7 +815,13 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // p (and k, c once known) are wave-uniform: telling the compiler moves the span / segment arithmetic that
         // derives from them to the scalar unit (the vector ALU is what the f32 MFMA competes for)
         p = __builtin_amdgcn_readfirstlane(p);
-        const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // Four signals per workgroup (128 VGPRs): the thread index is laundered once per atom.  Everything derived from it
+        // (LDS addresses of the windows, segment buffer, squares ...) is loop invariant; hoisted out of the atom loop it
+        // is live across the MFMA tile, gets spilled, and every reload is a scratch round trip on the atom's critical
+        // path.  Recomputing a few shifts and adds per atom is cheaper.
+        int tid = ltid();
+        if constexpr (GS > 1) asm volatile("" : "+v"(tid));
+        const int T = P.T, W = P.W, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int S4 = S4C > 0 ? S4C : A.S4;
         const Layout L = layout(P, A, lds);
         if (sh.nev >= P.cap) {                                  // event list full (uniform: LDS value)
@@ -975,8 +988,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
 
         HSCMP_MARK("tile");
         // ---- local re-correlation of the 2W-1 touched rows on the matrix cores (:1120, :1018-1051)
-        // (s_setprio does not help a signal's serial code against the other signals' tiles: measured, no effect --
-        // tools/serial_stretch_probe.hip.)
+        // Four waves per SIMD: serial code runs at priority 3, the tiles at priority 0.  Against waves that issue MFMAs
+        // back to back a raised priority buys nothing (tools/serial_stretch_probe.hip), but the tiles of this kernel wait
+        // for their LDS operands often enough that it is worth 2.5 % here (loop of config 2: 9.56 ms with, 9.84 without).
+        if constexpr (GS > 1 && !kLockstep) __builtin_amdgcn_s_setprio(0);
         for (int q = wv; q < ntiles; q += kWaves) {
             R sc;
             if constexpr (GS > 1 && S4C > 0) sc = Tile::template tile_score_lean<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
@@ -987,6 +1002,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                 L.sbs[t - segbase] = sc;
             }
         }
+        if constexpr (GS > 1 && !kLockstep) __builtin_amdgcn_s_setprio(3);
         HSCMP_STAMP(3);                                         // MFMA tile(s) of this wave
         // B4: per-row scores in the segment buffer
         if constexpr (kLockstep) { energy_partials(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
