@@ -311,6 +311,23 @@ template <> __device__ __forceinline__ Cand<float> wave_argmax<float>(Cand<float
     return r;
 }
 
+// Arg-max for candidates that are ORDERED BY LANE (every index a lane may hold is below every index of the next lane):
+// the first lane holding the maximal score holds the lowest index, so the second reduction of wave_argmax (minimum index
+// among the maxima: compare, select, six DPP steps, readlane -- all dependent) becomes a ballot, s_ff1 and one readlane.
+// Dependent vector instructions are what a wave waits for beside other waves' matrix instructions
+// (tools/serial_stretch_probe.hip), so the selection scans hand out contiguous index ranges per lane to qualify.
+template <typename R> __device__ __forceinline__ Cand<R> wave_argmax_first(Cand<R> c) { return wave_argmax(c); }
+template <> __device__ __forceinline__ Cand<float> wave_argmax_first<float>(Cand<float> c)
+{
+    Cand<float> r;
+    const int sb = __float_as_int(c.s);
+    const int mb = wave_max_i32(sb);
+    const unsigned long long holders = __ballot(sb == mb);
+    r.s = __int_as_float(mb);
+    r.i = __builtin_amdgcn_readlane(c.i, __ffsll((long long)holders) - 1);
+    return r;
+}
+
 template <typename R> __device__ __forceinline__ R wave_max(R v)
 {
 #pragma unroll

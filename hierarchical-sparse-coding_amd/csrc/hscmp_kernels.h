@@ -846,28 +846,25 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
             HSCMP_MARK("select");
             // :965-975 flat arg-max == arg-max over the segment maxima (ties: lowest t, then k)
             if constexpr (Recorr::kFused) {
-                // ONE wave scans the segment maxima and publishes the position; the others wait at an LDS barrier.  (The
-                // vector ALU is what the f32 MFMA tiles of the co-resident signals compete for: three waves that wait cost
-                // a handful of instructions, three redundant scans cost ~270.)
-                if (wv == 0) {
-                    Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
-                    for (int i = lane; i < P.nseg; i += 64) {         // ascending i per lane: '>' keeps the first of equals
+                // EVERY wave scans the segment maxima for itself: no barrier, nothing to publish.  (A barrier of this kernel
+                // is an LDS atomic plus at least one polling read, and beside the matrix instructions of the co-resident
+                // signals every LDS round trip of a wave takes ~1000 cycles -- tools/serial_stretch_probe.hip; the scan is
+                // one batch of reads and an arg-max.)  Lane l looks at the `per` consecutive segments from l * per on -- lanes
+                // in index order, see wave_argmax_first -- and carries the position of its best.
+                Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
+                const int per = (P.nseg + 63) >> 6;
+                for (int j = 0; j < per; ++j) {                       // ascending i per lane: '>' keeps the first of equals
+                    const int i = lane * per + j;
+                    if (i < P.nseg) {
                         const R sc = sh.seg_score[i];
-                        if (sc > c.s) { c.s = sc; c.i = i; }
+                        const int st = sh.seg_t[i];
+                        if (sc > c.s) { c.s = sc; c.i = st; }
                     }
-                    c = wave_argmax(c);
-                    if (lane == 0) { sh.atom_t = sh.seg_t[c.i]; sh.atom_k = c.i; }
                 }
-                sy.lds();
-                p_sel = __builtin_amdgcn_readfirstlane(sh.atom_t);
-                const int sg = __builtin_amdgcn_readfirstlane(sh.atom_k);      // (the winning segment)
-                (void)sg;
-                if constexpr (Recorr::kScoreOnly) {
-                    nsel = 1;              // (k, c) and the null test (:974) are resolved inside apply_atom
-                } else {
-                    k_sel = sh.seg_k[sg]; c_sel = sh.seg_c[sg];
-                    nsel = (has_thres && !(fabs((double)c_sel) > thres)) ? 0 : 1;     // :974
-                }
+                c = wave_argmax_first(c);
+                p_sel = c.i;
+                static_assert(Recorr::kScoreOnly, "the fused atom body resolves (k, c) itself");
+                nsel = 1;                  // (k, c) and the null test (:974) are resolved inside apply_atom
             } else {
                 Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
                 for (int i = tid; i < P.nseg; i += kThreads) {

@@ -115,13 +115,27 @@ __device__ __forceinline__ void mfma_reduce_pair(float v0, float v1, int k0, int
 #endif
 }
 
+// The group hint: next to the score the tile reports WHICH 32-atom group holds the first atom that attains it (two
+// vector instructions per group: did the running maximum grow while this group was reduced?).  When the position is
+// selected, a wave recomputes that group's rows only -- 32 chains, one per lane, instead of K spread over the
+// workgroup -- and needs nobody else's result (see resolve_group).
+__device__ __forceinline__ void mfma_merge_halves(float& bs, int& bg, int h)
+{
+    // the two half-waves hold the same position with interleaved atom sets: larger score, on a tie the lower group
+    const float os = swap_halves_f(bs, h);
+    const int og = swap_halves_i(bg, h);
+    bg = (os > bs || (os == bs && og < bg)) ? og : bg;
+    bs = fmaxf(bs, os);
+}
+
 template <int S4C, bool HAS_W>
 __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg, const float* __restrict__ win,
-                                                 const float* __restrict__ wts, int G, int S4rt, int lane)
+                                                 const float* __restrict__ wts, int G, int S4rt, int lane, int& grp)
 {
     const int j = lane & 31, h = lane >> 5;
     const float* wb = win + j + h;
     float bs = 0.0f;                           // scores are >= 0
+    int bg = 0;
     const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
     // atom of accumulator element r: 32g + 4h + (r&3) + 8(r>>2); pair (2e, 2e+1) shares one v_max3
     auto katom = [&](int kbase, int r) { return kbase + (r & 3) + 8 * (r >> 2); };
@@ -151,7 +165,9 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
         };
         // MFMA chain of one group into `acc`; the 8 reduction steps of the previous group's
         // accumulator `accp` are spread between the MFMA issues
-        auto run_next = [&](const f32x4 (&a)[S4C], f32x16& acc, const f32x16& accp, int kbasep) {
+        auto run_next = [&](const f32x4 (&a)[S4C], f32x16& acc, const f32x16& accp, int gp) {
+            const int kbasep = 32 * gp + 4 * h;
+            const float before = bs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
@@ -161,13 +177,16 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
                 for (int e = (m * 8) / NM; e < ((m + 1) * 8) / NM; ++e)
                     mfma_reduce_pair<HAS_W>(accp[2 * e], accp[2 * e + 1], katom(kbasep, 2 * e), katom(kbasep, 2 * e + 1), wts, bs);
             }
+            bg = bs > before ? gp : bg;
         };
-        auto reduce_all = [&](const f32x16& acc, int kbase) {
+        auto reduce_all = [&](const f32x16& acc, int gl) {
+            const int kbase = 32 * gl + 4 * h;
+            const float before = bs;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(kbase, 2 * e), katom(kbase, 2 * e + 1), wts, bs);
+            bg = bs > before ? gl : bg;
         };
-        const int kb0 = 4 * h;
 
         load_a(a0, 0);
         if (G > 1) load_a(a1, 1);
@@ -175,15 +194,15 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
         int g = 1;
         for (; g + 1 < G; g += 2) {
             load_a(a0, g + 1);
-            run_next(a1, acc1, acc0, 32 * (g - 1) + kb0);
+            run_next(a1, acc1, acc0, g - 1);
             if (g + 2 < G) load_a(a1, g + 2);
-            run_next(a0, acc0, acc1, 32 * g + kb0);
+            run_next(a0, acc0, acc1, g);
         }
         if (g < G) {
-            run_next(a1, acc1, acc0, 32 * (g - 1) + kb0);
-            reduce_all(acc1, 32 * g + kb0);
+            run_next(a1, acc1, acc0, g - 1);
+            reduce_all(acc1, g);
         } else {
-            reduce_all(acc0, 32 * (G - 1) + kb0);
+            reduce_all(acc0, G - 1);
         }
     } else {
         const int S4 = S4rt;
@@ -200,41 +219,51 @@ __device__ __forceinline__ float mfma_tile_score(const float* __restrict__ dimg,
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
             }
             const int kbase = 32 * g + 4 * h;
+            const float before = bs;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(kbase, 2 * e), katom(kbase, 2 * e + 1), wts, bs);
+            bg = bs > before ? g : bg;
         }
     }
-    // the two half-waves hold the same position with interleaved atom sets
-    return fmaxf(bs, swap_halves_f(bs, h));
+    mfma_merge_halves(bs, bg, h);
+    grp = bg;
+    return bs;
 }
 
 // The same tile for a kernel that runs FOUR waves per SIMD (128 VGPRs per lane; MfmaRecorr with four signals per
-// workgroup): neither the 32 B operands nor a group's 32 A operands stay in registers -- both are read from LDS one
-// chunk (4 k-steps) ahead of the MFMAs that use them, which costs LDS issue slots but no matrix-pipe time, and the
-// other three waves of the SIMD cover the latency.  Two accumulators alternate, so the 8 v_max3 of group g-1 sit
-// between the MFMAs of group g.  Same products, same order: bit-identical to mfma_tile_score.
+// workgroup).  Neither the 32 B operands nor a group's 32 A operands stay in registers: both stream from LDS one chunk
+// (4 MFMAs) ahead of their use -- no MFMA waits for a read issued right in front of it: in the greedy loop fewer than
+// four waves of a SIMD are inside a tile at any time, and what one wave waits for nobody covers.  Two accumulators alternate, so the 8
+// v_max3 of group g-1 sit between the MFMAs of group g.  Nothing is scheduled across a chunk boundary (left alone the
+// scheduler hoists the operand reads of several chunks, the tile then wants 145 VGPRs by itself and the kernel around
+// it spills).  Same products, same order: bit-identical to mfma_tile_score.
 template <int S4C, bool HAS_W>
 __device__ __forceinline__ float mfma_tile_score_lean(const float* __restrict__ dimg, const float* __restrict__ win,
-                                                      const float* __restrict__ wts, int G, int lane)
+                                                      const float* __restrict__ wts, int G, int lane, int& grp)
 {
     static_assert(S4C > 0, "compile-time chunk count only");
     const int j = lane & 31, h = lane >> 5;
     const float* wb = win + j + h;
     const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
     float bs = 0.0f;
+    int bg = 0;
     auto katom = [&](int kbase, int r) { return kbase + (r & 3) + 8 * (r >> 2); };
     const int kb0 = 4 * h;
+    f32x4 a = dv[0];                                            // chunk 0 of group 0
+    float b0 = wb[0], b1 = wb[2], b2 = wb[4], b3 = wb[6];
     // MFMA chain of group g into `acc`; with REDUCE the 8 reduction steps of the previous group's finished
-    // accumulator `accp` sit between the MFMAs (first MFMA of a chain: C = 0)
+    // accumulator `accp` sit between the MFMAs (first MFMA of a chain: C = 0).  Leaves `a` = chunk 0 of group g+1.
     auto chain = [&](int g, f32x16& acc, const f32x16& accp, auto reduce_tag) {
         constexpr bool REDUCE = decltype(reduce_tag)::value;
-        f32x4 a = dv[(g * S4C) * 64];
+        const float before = bs;
 #pragma unroll
         for (int s4 = 0; s4 < S4C; ++s4) {
-            f32x4 an = a;
-            if (s4 + 1 < S4C) an = dv[(g * S4C + s4 + 1) * 64];     // the next chunk's A operands, in flight under this chunk's MFMAs
-            const float b0 = wb[8 * s4 + 0], b1 = wb[8 * s4 + 2], b2 = wb[8 * s4 + 4], b3 = wb[8 * s4 + 6];
+            // the next chunk's A operands (the next group's first chunk behind the last one; one chunk past the image
+            // for the last group: inside the LDS allocation, never used), in flight under this chunk's MFMAs
+            const f32x4 an = dv[(g * S4C + s4 + 1) * 64];
+            const int sn = (s4 + 1) % S4C;                      // B operands: the same 4 * S4C values for every group
+            const float bn0 = wb[8 * sn + 0], bn1 = wb[8 * sn + 2], bn2 = wb[8 * sn + 4], bn3 = wb[8 * sn + 6];
             if (s4 == 0) {
                 f32x16 zero;
 #pragma unroll
@@ -251,18 +280,19 @@ __device__ __forceinline__ float mfma_tile_score_lean(const float* __restrict__ 
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b3, acc, 0, 0, 0);
-            a = an;
+            a = an; b0 = bn0; b1 = bn1; b2 = bn2; b3 = bn3;
 #ifndef HSCMP_LEAN_NO_SCHED_BARRIER
-            // nothing moves across a chunk boundary: left alone the scheduler hoists the operand reads of several chunks
-            // ahead (the tile then wants 145 VGPRs by itself and the kernel around it spills)
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+        if constexpr (REDUCE) bg = bs > before ? g - 1 : bg;
     };
     auto reduce_all = [&](const f32x16& acc, int g) {
+        const float before = bs;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             mfma_reduce_pair<HAS_W>(acc[2 * e], acc[2 * e + 1], katom(32 * g + kb0, 2 * e), katom(32 * g + kb0, 2 * e + 1), wts, bs);
+        bg = bs > before ? g : bg;
     };
     f32x16 acc0, acc1;
     chain(0, acc0, acc0, std::false_type());
@@ -278,7 +308,9 @@ __device__ __forceinline__ float mfma_tile_score_lean(const float* __restrict__ 
     } else {
         reduce_all(acc0, G - 1);
     }
-    return fmaxf(bs, swap_halves_f(bs, h));
+    mfma_merge_halves(bs, bg, h);
+    grp = bg;
+    return bs;
 }
 
 __device__ __forceinline__ void lds_copy16(void* dst, const void* __restrict__ src, int nbytes, int tid = (int)threadIdx.x, int nthreads = kThreads)
@@ -369,9 +401,13 @@ __global__ __launch_bounds__(kThreads) void corr_init_mfma_kernel(DevParams P, S
         const int npos = min(kMfmaChunk, T - c0);
         const int ntiles = (npos + TP - 1) / TP;
         for (int q = wv; q < ntiles; q += kWaves) {
-            const R sc = Tile::template tile_score<S4C, HAS_W>(dimg, xs + TP * q, wts, G, S4, lane);
+            int grp;
+            const R sc = Tile::template tile_score<S4C, HAS_W>(dimg, xs + TP * q, wts, G, S4, lane, grp);
             const int t = c0 + TP * q + lane;
-            if (lane < TP && t < T) S.best_c[(int64_t)b * T + t] = sc;      // score-only state (see mfma_tile_score)
+            if (lane < TP && t < T) {                                       // score-only state (see mfma_tile_score)
+                S.best_c[(int64_t)b * T + t] = sc;
+                S.best_k[(int64_t)b * T + t] = grp;                         // the group hint, not an atom
+            }
         }
         __syncthreads();                                // all tiles read xs before it is overwritten
     }
@@ -508,11 +544,12 @@ __device__ __forceinline__ double resolve_chain_f64(const double* __restrict__ d
 
 template <int S4C, bool HAS_W>
 __device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__ dimg, const double* __restrict__ win,
-                                                      const double* __restrict__ wts, int G, int S4rt, int lane)
+                                                      const double* __restrict__ wts, int G, int S4rt, int lane, int& grp)
 {
     const int j = lane & 15, kk = lane >> 4;
     const double* wb = win + j + kk;
     double bs = 0.0;
+    int bg = 0;                                // group hint, see mfma_tile_score (16-atom groups here)
     const f64x2* dv = reinterpret_cast<const f64x2*>(dimg) + lane;
     auto reduce_elem = [&](double v, int k) {
         if (HAS_W) v = v * wts[k];
@@ -534,7 +571,9 @@ __device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m >> 1][m & 1], bop[m], acc, 0, 0, 0);
         };
-        auto run_next = [&](const f64x2 (&a)[S4C], f64x4& acc, const f64x4& accp, int kbasep) {
+        auto run_next = [&](const f64x2 (&a)[S4C], f64x4& acc, const f64x4& accp, int gp) {
+            const int kbasep = 16 * gp + kk;
+            const double before = bs;
             acc = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -542,10 +581,13 @@ __device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__
 #pragma unroll
                 for (int e = (m * 4) / NM; e < ((m + 1) * 4) / NM; ++e) reduce_elem(accp[e], kbasep + 4 * e);
             }
+            bg = bs > before ? gp : bg;
         };
-        auto reduce_all = [&](const f64x4& acc, int kbase) {
+        auto reduce_all = [&](const f64x4& acc, int gl) {
+            const double before = bs;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) reduce_elem(acc[e], kbase + 4 * e);
+            for (int e = 0; e < 4; ++e) reduce_elem(acc[e], 16 * gl + kk + 4 * e);
+            bg = bs > before ? gl : bg;
         };
         load_a(a0, 0);
         if (G > 1) load_a(a1, 1);
@@ -553,15 +595,15 @@ __device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__
         int g = 1;
         for (; g + 1 < G; g += 2) {
             load_a(a0, g + 1);
-            run_next(a1, acc1, acc0, 16 * (g - 1) + kk);
+            run_next(a1, acc1, acc0, g - 1);
             if (g + 2 < G) load_a(a1, g + 2);
-            run_next(a0, acc0, acc1, 16 * g + kk);
+            run_next(a0, acc0, acc1, g);
         }
         if (g < G) {
-            run_next(a1, acc1, acc0, 16 * (g - 1) + kk);
-            reduce_all(acc1, 16 * g + kk);
+            run_next(a1, acc1, acc0, g - 1);
+            reduce_all(acc1, g);
         } else {
-            reduce_all(acc0, 16 * (G - 1) + kk);
+            reduce_all(acc0, G - 1);
         }
     } else {
         const int S4 = S4rt;
@@ -572,13 +614,21 @@ __device__ __forceinline__ double mfma_tile_score_f64(const double* __restrict__
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], wb[8 * c], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], wb[8 * c + 4], acc, 0, 0, 0);
             }
+            const double before = bs;
 #pragma unroll
             for (int e = 0; e < 4; ++e) reduce_elem(acc[e], 16 * g + kk + 4 * e);
+            bg = bs > before ? g : bg;
         }
     }
-    // the four 16-lane quarters hold the same position with interleaved atom sets
-    bs = fmax(bs, __shfl_xor(bs, 16));
-    bs = fmax(bs, __shfl_xor(bs, 32));
+    // the four 16-lane quarters hold the same position with interleaved atom sets: larger score, on a tie the lower group
+#pragma unroll
+    for (int x = 16; x <= 32; x <<= 1) {
+        const double os = __shfl_xor(bs, x);
+        const int og = __shfl_xor(bg, x);
+        bg = (os > bs || (os == bs && og < bg)) ? og : bg;
+        bs = fmax(bs, os);
+    }
+    grp = bg;
     return bs;
 }
 
@@ -591,11 +641,11 @@ struct TileF32 {
     static constexpr size_t kMaxImageBytes = 64 * 1024; // two workgroups per CU
     static int groups(int K) { return (K + 31) / 32; }
     template <int S4C, bool HAS_W>
-    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
-    { return mfma_tile_score<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane, int& grp)
+    { return mfma_tile_score<S4C, HAS_W>(dimg, win, wts, G, S4, lane, grp); }
     template <int S4C, bool HAS_W>
-    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int, int lane)
-    { return mfma_tile_score_lean<S4C, HAS_W>(dimg, win, wts, G, lane); }
+    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int, int lane, int& grp)
+    { return mfma_tile_score_lean<S4C, HAS_W>(dimg, win, wts, G, lane, grp); }
     template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
     { return resolve_chain<S4C>(dimg, rwin, k, S4); }
     static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index(k, w, S4); }
@@ -608,11 +658,11 @@ struct TileF64 {
     static constexpr size_t kMaxImageBytes = 128 * 1024; // one workgroup per CU
     static int groups(int K) { return (K + 15) / 16; }
     template <int S4C, bool HAS_W>
-    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
-    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }
+    static __device__ __forceinline__ R tile_score(const R* dimg, const R* win, const R* wts, int G, int S4, int lane, int& grp)
+    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane, grp); }
     template <int S4C, bool HAS_W>
-    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int S4, int lane)
-    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane); }      // (no four-signal form for float64)
+    static __device__ __forceinline__ R tile_score_lean(const R* dimg, const R* win, const R* wts, int G, int S4, int lane, int& grp)
+    { return mfma_tile_score_f64<S4C, HAS_W>(dimg, win, wts, G, S4, lane, grp); }      // (no four-signal form for float64)
     template <int S4C> static __device__ __forceinline__ R resolve(const R* dimg, const R* rwin, int k, int S4)
     { return resolve_chain_f64<S4C>(dimg, rwin, k, S4); }
     static __device__ __forceinline__ int dindex(int k, int w, int S4) { return dimg_index_f64(k, w, S4); }
@@ -786,22 +836,34 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         const int S4 = S4C > 0 ? S4C : A.S4;
         R* rw = L.rwin_w + (ltid() >> 6) * L.wp;
         __builtin_amdgcn_wave_barrier();
+        const int gh = Gs.bk[t];                            // the hint travels with the window's samples
         for (int w = lane; w < P.W; w += 64) rw[w] = edge_window_value(Gs.r, P.T, t - P.off + w, t, L.edge);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
-        R bc = (R)0;
-        for (int k = lane; k < P.K; k += 64) {
-            const R acc = Tile::template resolve<S4C>(L.dimg, rw, k, S4);
-            R sc;
-            if (HAS_W) { const R sw = acc * L.wts[k]; sc = rabs(sw); } else sc = rabs(acc);
-            if (sc > best.s) { best.s = sc; best.i = k; bc = acc; }
-        }
-        best = wave_argmax(best);
-        k_out = best.i;
-        c_out = wave_bcast(bc, best.i & 63);
+        resolve_group(P, L, rw, gh, lane, S4, k_out, c_out);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+    }
+
+    // (k, c) of a position from its window `rw` (LDS, this wave's strip): the tile that wrote the position's score also
+    // wrote which atom group holds the first atom attaining it (`hint` = the loaded Gs.bk[t], uniform; see
+    // mfma_tile_score), so one chain per lane over that group's atoms is all there is to recompute; first k wins ties
+    // (:970).  One wave, nobody else's data: result in every lane.
+    static __device__ __forceinline__ void resolve_group(const DevParams& P, const Layout& L, const R* rw,
+                                                         int hint, int lane, int S4, int& k_out, R& c_out)
+    {
+        const int g = __builtin_amdgcn_readfirstlane(hint);
+        const int k = Tile::GA * g + lane;
+        Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+        R bc = (R)0;
+        if (lane < Tile::GA && k < P.K) {
+            bc = Tile::template resolve<S4C>(L.dimg, rw, k, S4);
+            if (HAS_W) { const R sw = bc * L.wts[k]; best.s = rabs(sw); } else best.s = rabs(bc);
+            best.i = k;
+        }
+        best = wave_argmax_first(best);                     // (lane l holds atom GA*g + l: lanes in index order)
+        k_out = best.i;
+        c_out = wave_bcast(bc, best.i & (Tile::GA - 1));
     }
 
     // One applied atom at position p: modeling.py:1106-1142.  resolved: (k, c) already known (blocked
@@ -847,14 +909,40 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         if (resolved) { k = __builtin_amdgcn_readfirstlane(k); c = wave_bcast(c, 0); }
         HSCMP_MARK("A_loads");
         // ---- phase A: every global load of this atom, issued together -------------------------
-        R rv[2]; int rm[2];
+        // first what the longest chain of the atom waits for: the position's window and its group hint.  EVERY wave
+        // loads them and resolves (k, c) for itself (64 samples and one word, four times): no barrier, no exchange
+        // Compile-time chunk count: W <= 8 * S4C bounds the span (3W - 2) and the window (W), so a kernel built for
+        // W <= 64 has no second pass over either.  And away from the signal ends -- a uniform branch, almost every
+        // atom -- there is no reflection (an integer modulo on the vector ALU) and no edge history to consult.
+        constexpr int kUS = (S4C > 0 && 24 * S4C - 2 <= kThreads) ? 1 : 2;      // passes over the span
+        constexpr int kUW = (S4C > 0 && 8 * S4C <= 64) ? 1 : 2;                 // passes over the window
+        int gh = 0;
+        R wres[2] = {(R)0, (R)0};                               // W <= 128: two taps per lane
+        R rv[2] = {(R)0, (R)0}; int rm[2] = {-1, -1};
+        if (interior) {
+            if (!resolved) {
+                gh = Gs.bk[p];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * kThreads;
-            rm[u] = -1; rv[u] = (R)0;
-            if (i < span) {                                     // np.pad 'reflect', :1046 (identity away from the edges)
-                rm[u] = interior ? tstart + i : reflect_index(tstart + i, sidx, nslice);
-                rv[u] = Gs.r[rm[u]];
+                for (int u = 0; u < kUW; ++u) if (lane + 64 * u < W) wres[u] = Gs.r[p - P.off + lane + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < kUS; ++u) {
+                const int i = tid + u * kThreads;
+                if (i < span) { rm[u] = tstart + i; rv[u] = Gs.r[rm[u]]; }
+            }
+        } else {
+            if (!resolved) {
+                gh = Gs.bk[p];
+#pragma unroll
+                for (int u = 0; u < kUW; ++u) if (lane + 64 * u < W) wres[u] = edge_window_value(Gs.r, T, p - P.off + lane + 64 * u, p, L.edge);
+            }
+#pragma unroll
+            for (int u = 0; u < kUS; ++u) {
+                const int i = tid + u * kThreads;
+                if (i < span) {                                 // np.pad 'reflect', :1046
+                    rm[u] = reflect_index(tstart + i, sidx, nslice);
+                    rv[u] = Gs.r[rm[u]];
+                }
             }
         }
         R os[2];
@@ -863,9 +951,6 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             const int i = tid + u * kThreads;
             os[u] = (R)0;
             if (i < nsb) os[u] = Gs.bc[segbase + i];            // old scores of the touched segments
-        }
-        if (!resolved) {
-            if (tid < W) L.rwin[tid] = edge_window_value(Gs.r, T, p - P.off + tid, p, L.edge);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -879,24 +964,13 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         HSCMP_MARK("resolve");
         // ---- resolve (k, c) of the selected position (:970) ------------------------------------
         if (!resolved) {
-            sy.lds();                                      // Bx: the position's window is in LDS
-            Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
-            R bc = (R)0;
-            for (int kk = tid; kk < P.K; kk += kThreads) {
-                const R acc = Tile::template resolve<S4C>(L.dimg, L.rwin, kk, S4);
-                R sc;
-                if (HAS_W) { const R sw = acc * L.wts[kk]; sc = rabs(sw); } else sc = rabs(acc);
-                if (sc > best.s) { best.s = sc; best.i = kk; bc = acc; }
-            }
-            const Cand<R> wbest = wave_argmax(best);
-            if (best.i == wbest.i && wbest.i != INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = bc; }   // the owner lane
-            if (lane == 0 && wbest.i == INT_MAX) { sh.cred[wv] = wbest; sh.red[wv] = (R)0; }
-            sy.lds();                                      // By
-            Cand<R> m = sh.cred[0];
-            c = sh.red[0];
+            R* rw = L.rwin_w + wv * L.wp;                   // this wave's strip
 #pragma unroll
-            for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) { m = sh.cred[q]; c = sh.red[q]; }
-            k = __builtin_amdgcn_readfirstlane(m.i);
+            for (int u = 0; u < kUW; ++u) if (lane + 64 * u < W) rw[lane + 64 * u] = wres[u];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            resolve_group(P, L, rw, gh, lane, S4, k, c);
+            k = __builtin_amdgcn_readfirstlane(k);
             c = wave_bcast(c, 0);
             if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
                 // (with a residual-scale rule the reference tests that rule first, :1145-1153: the slow rules name the reason)
@@ -930,8 +1004,33 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // ---- residual subtract (:1117, :996-1016) on the register copy; window + squares to LDS
         const R nc = -c;
         bool own[2] = {false, false};                           // this thread owns the sample itself: it stores the new value
+        if (interior) {                                         // no reflected copies, no edge history
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < kUS; ++u) {
+                const int i = tid + u * kThreads;
+                if (i < span) {
+                    R v = rv[u];
+                    const int q = rm[u] - s;
+                    if (q >= 0 && q < e - s) {
+                        const R prod = nc * L.dimg[Tile::dindex(k, es + q, S4)];   // -c*D[k] rounded, then += (utils.py:120,129)
+                        const R vn = v + prod;
+                        // (W = 2 only: the atom at T-1-W is an interior one, see the stale-sample note below)
+                        if (!(W & 1) && p == T - 1 - W && rm[u] == T - 1 - W / 2 && (L.edge[1] & 1ull) && L.edge[2] == 0ull) {
+                            L.edge[3] = edge_bits_of(v);
+                            L.edge[2] = (unsigned long long)(rm[u] + 1);
+                        }
+                        own[u] = true;
+                        L.esq[q] = v * v;
+                        L.esq[L.wp + q] = vn * vn;
+                        v = vn;
+                    }
+                    L.win[i] = v;
+                    rv[u] = v;
+                }
+            }
+        } else
+#pragma unroll
+        for (int u = 0; u < kUS; ++u) {
             const int i = tid + u * kThreads;
             if (i < span) {
                 R v = rv[u];
@@ -969,7 +1068,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // barrier late would load the sample after it had changed and subtract the atom from it a second time.  Every
         // thread has consumed what it loaded before it arrives here (its window entry depends on it).
 #pragma unroll
-        for (int u = 0; u < 2; ++u) if (own[u]) Gs.r[rm[u]] = rv[u];
+        for (int u = 0; u < kUS; ++u) if (own[u]) Gs.r[rm[u]] = rv[u];
         if (P.has_scale) {                                      // toleranceResidualScale: max|r| of touched segments
             sy.full();                                          // (the stores above are visible to the scan)
             for (int sg = (s >> P.seg_shift) + wv; sg <= ((e - 1) >> P.seg_shift); sg += kWaves) rscan_segment(P, Gs, sh, sg, lane);
@@ -979,8 +1078,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // local energy before / after (:1002-1005): pinned tree, partial q lives in thread q
         auto energy_partials = [&]() {
             R pb = (R)0, pa = (R)0;
-            if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
-            wave_tree_down2(pb, pa);
+            if (wv * 64 < len) {                                // (a wave without samples: its tree of zeros sums to +0)
+                if (tid < len) { pb = L.esq[tid]; pa = L.esq[L.wp + tid]; }
+                wave_tree_down2(pb, pa);
+            }
             if (lane == 0) { sh.red[wv] = pb; sh.red[kWaves + wv] = pa; }
         };
         if constexpr (!kLockstep) energy_partials();
@@ -994,11 +1095,13 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         if constexpr (GS > 1 && !kLockstep) __builtin_amdgcn_s_setprio(0);
         for (int q = wv; q < ntiles; q += kWaves) {
             R sc;
-            if constexpr (GS > 1 && S4C > 0) sc = Tile::template tile_score_lean<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
-            else sc = Tile::template tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane);
+            int grp;
+            if constexpr (GS > 1 && S4C > 0) sc = Tile::template tile_score_lean<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane, grp);
+            else sc = Tile::template tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4, lane, grp);
             const int row = TP * q + lane, t = p - (W - 1) + row;
             if (lane < TP && row < nrows && t >= 0 && t < T) {  // overlapReplace clipping (utils.py:133-161)
                 Gs.bc[t] = sc;
+                Gs.bk[t] = grp;                                 // the group hint of the row (resolve_group)
                 L.sbs[t - segbase] = sc;
             }
         }
@@ -1014,11 +1117,15 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) {
             const int t0 = (sg << P.seg_shift), t1 = min(T, t0 + P.seg);
             Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
-            for (int t = t0 + lane; t < t1; t += 64) {
-                const R sc = L.sbs[t - segbase];
-                if (sc > best.s) { best.s = sc; best.i = t; }
+            const int per = P.seg >> 6;                         // consecutive positions per lane (wave_argmax_first)
+            for (int j = 0; j < per; ++j) {
+                const int t = t0 + lane * per + j;
+                if (t < t1) {
+                    const R sc = L.sbs[t - segbase];
+                    if (sc > best.s) { best.s = sc; best.i = t; }
+                }
             }
-            best = wave_argmax(best);
+            best = wave_argmax_first(best);
             if (lane == 0) { sh.seg_score[sg] = best.s; sh.seg_t[sg] = best.i; }
         }
         HSCMP_MARK("bookkeeping");

@@ -24,10 +24,11 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD, WAVES_PER_SIMD) void tiles(co
     float acc = 0.0f; int gacc = 0;
     for (int it = 0; it < iters; ++it) {
         float sc;
+        int grp;
         const float* w = win + 224 * (wave & 15) + 32 * (it & 3);
-        if constexpr (FORM == 0) sc = mfma_tile_score_lean<8, false>(dimg, w, nullptr, 8, lane);
-        else sc = mfma_tile_score<8, false>(dimg, w, nullptr, 8, 8, lane);
-        acc += sc;
+        if constexpr (FORM == 0) sc = mfma_tile_score_lean<8, false>(dimg, w, nullptr, 8, lane, grp);
+        else sc = mfma_tile_score<8, false>(dimg, w, nullptr, 8, 8, lane, grp);
+        acc += sc; gacc += grp;
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc + (float)gacc;
 }
@@ -56,8 +57,10 @@ int main()
     float* img; float* out;
     hipMalloc(&img, 65536); hipMemset(img, 0, 65536);
     hipMalloc(&out, 256 * 1024 * 4);
-    run<0, 4>("lean tile (A one chunk ahead, B at use)", img, out);
+    run<0, 4>("lean tile (B in registers, A one chunk ahead)", img, out);
+    run<0, 3>("lean tile (B in registers, A one chunk ahead)", img, out);
+    run<0, 1>("lean tile (B in registers, A one chunk ahead)", img, out);
     run<1, 2>("full tile (B in registers, A a group ahead)", img, out);
-    run<0, 2>("lean tile (A one chunk ahead, B at use)", img, out);
+    run<0, 2>("lean tile (B in registers, A one chunk ahead)", img, out);
     return 0;
 }
