@@ -286,10 +286,13 @@ def bench_cmp(args, ctx):
     gather = None
     if world > 1:
         t2 = time.perf_counter()
-        g = parallel.gather_results(eng, device=dev if args.backend == 'nccl' else None)
-        if args.backend == 'nccl':
-            torch.cuda.synchronize(dev)
-        gather = {'ms': 1e3 * (time.perf_counter() - t2), 'bytes_per_signal': g['bytes_per_signal'], 'signals': int(g['stats'].shape[0])}
+        try:                              # (reported beside the metric, never part of it: a failure here must not cost the line)
+            g = parallel.gather_results(eng, device=dev if args.backend == 'nccl' else None)
+            if args.backend == 'nccl':
+                torch.cuda.synchronize(dev)
+            gather = {'ms': 1e3 * (time.perf_counter() - t2), 'bytes_per_signal': g['bytes_per_signal'], 'signals': int(g['stats'].shape[0])}
+        except Exception as ex:
+            gather = {'error': '%s: %s' % (type(ex).__name__, ex)}
 
     elapsed_max, nsel_total = reduce_over_ranks(ctx, args, elapsed, nsel_local)
     if rank != 0:

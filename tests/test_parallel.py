@@ -123,3 +123,18 @@ def test_dictionary_broadcast_is_a_tensor_broadcast(tmp_path):
     a, b = (np.load(os.path.join(str(tmp_path), 'bcast%d.npz' % r)) for r in (0, 1))
     assert a['D'].dtype == np.float64 and a['D'].shape == (6, 5, 3)
     assert np.array_equal(a['D'], b['D']) and np.array_equal(a['w'], b['w'])
+
+
+@pytest.mark.gpu
+def test_gather_from_device_buffers_under_nccl():
+    """The `nccl` leg of hsc_amd.parallel on the GPU box's one GPU (a one-rank process group, in a child process): the
+    gather runs on device tensors that are views of the engine's buffers, the broadcast on a device tensor."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_child.py')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'NCCL-CHILD-OK' in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
