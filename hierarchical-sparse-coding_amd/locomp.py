@@ -108,7 +108,9 @@ class LoCOMP(ConvolutionalMatchingPursuit):
         energySignal = np.sum(np.square(sequence))
         residual = np.copy(sequence)
         energyResidual = energySignal
-        coefficients = scipy.sparse.lil_matrix((sequence.shape[0], D.shape[0]))
+        # (a dictionary-of-keys matrix: the same `coefficients[t, k] += c` / `.nnz` / `.tocoo()` behaviour as the reference's
+        # list-of-lists matrix, without the T empty row lists -- 17 ms to build at T = 65536)
+        coefficients = scipy.sparse.dok_matrix((sequence.shape[0], D.shape[0]), dtype=np.float64)
         self._support = (coefficients, [], {})
         innerProducts = self._initialInnerProducts(residual, D, dt)                                                   # :1293
 
@@ -169,10 +171,9 @@ class LoCOMP(ConvolutionalMatchingPursuit):
         if minCoefficients is not None:                                           # :1411-1417
             cx = coefficients.tocoo()
             keep = np.abs(cx.data) >= minCoefficients
-            clipped = scipy.sparse.lil_matrix((sequence.shape[0], D.shape[0]))
-            clipped[cx.row[keep], cx.col[keep]] = cx.data[keep]
-            coefficients = clipped
-        coefficients = coefficients.tocsc()
+            coefficients = scipy.sparse.coo_matrix((cx.data[keep], (cx.row[keep], cx.col[keep])), shape=cx.shape)
+        coefficients = scipy.sparse.csc_matrix(coefficients)
+        coefficients.sum_duplicates()
         coefficients.eliminate_zeros()
         if squeezeOutput:
             residual = np.squeeze(residual, axis=1)
