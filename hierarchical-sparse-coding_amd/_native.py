@@ -171,8 +171,29 @@ class DeviceTable(object):
         self.engine = engine
         self.shape = (T, engine.K)
         self.dtype = engine.dtype
+        self._pending = None              # (lo, hi, residual, [centres]): updates not yet sent to the device
+
+    def defer_update(self, residual, lo, hi, centres):
+        """Record an update (residual samples [lo, hi) changed, rows around `centres` to be re-correlated).  Nothing
+        reads the table before the next selection, and a row's value only depends on the residual samples of its
+        window, all of which are final by then -- so the updates of a selection round go to the device as ONE call
+        (the union of the sample ranges, all centres) instead of one per atom."""
+        if self._pending is None:
+            self._pending = [lo, hi, residual, list(centres)]
+        else:
+            self._pending[0] = min(self._pending[0], lo)
+            self._pending[1] = max(self._pending[1], hi)
+            self._pending[2] = residual
+            self._pending[3].extend(centres)
+
+    def flush(self):
+        if self._pending is not None:
+            lo, hi, residual, centres = self._pending
+            self._pending = None
+            self.engine.table_update(residual[lo:hi], lo, centres)
 
     def read(self):
+        self.flush()
         return self.engine.table_read(table=True)[0]
 
 

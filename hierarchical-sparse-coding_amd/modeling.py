@@ -208,6 +208,7 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         if weights is not None:
             assert len(weights) == innerProducts.shape[1]
         if isinstance(innerProducts, _native.DeviceTable):          # the table lives on the device: nothing to upload
+            innerProducts.flush()                                   # (the deferred updates of the previous round)
             t, k, c = innerProducts.engine.table_select(nbBlocks, offset, nullCoeffThres, weights)
             return [Atom(int(p), int(f), cc, filterWidth) for p, f, cc in zip(t, k, c)]
         dt = _compute_dtype(innerProducts.dtype)
@@ -246,7 +247,7 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
             # the rows around every atom are recomputed where the table lives
             spans = [centered_span(residual.shape[0], a.length, a.position)[:2] for a in atoms]
             lo, hi = min(s for s, _ in spans), max(e for _, e in spans)
-            innerProducts.engine.table_update(residual[lo:hi], lo, [a.position for a in atoms])
+            innerProducts.defer_update(residual, lo, hi, [a.position for a in atoms])
             return innerProducts
         dt = _compute_dtype(innerProducts.dtype, D.dtype)
         if innerProducts.dtype != dt or not innerProducts.flags.c_contiguous:

@@ -129,6 +129,7 @@ def test_device_resident_table_equals_host_table_ops(dtype):
         cmp._updateInnerProducts(tab, residual, atoms, D)
         for a in atoms:
             orc.update_inner_products(ip, residual, D, a.position)
+        tab.flush()                                             # (updates are deferred to the next selection: send them now)
         tb, rb = eng.table_read(table=True, residual=True)
         assert np.array_equal(tb, ip), rnd
         assert np.array_equal(rb, residual), rnd
