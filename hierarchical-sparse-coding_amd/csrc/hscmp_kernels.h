@@ -390,7 +390,22 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     int atom_t, atom_k;
     R atom_c;
     R e_sig, e_res;
+    // fused atom bodies: {converged, events, slots, hashed} as of the end of the last atom, written by the bookkeeping
+    // lane in front of the atom's last barrier.  Every wave fetches it with ONE 16-byte read behind that barrier and
+    // carries it in scalar registers (FusedCtl): beside the matrix instructions of co-resident signals each LDS round trip
+    // of a wave costs ~1000 cycles, and the control flow between two atoms used to make five of them, one after another.
+    alignas(16) int ctl[4];
 };
+
+struct FusedCtl { int converged, nev, nslots, hashed; };
+template <typename SH> __device__ __forceinline__ FusedCtl fused_ctl_fetch(const SH& sh)
+{
+    const int4 v = *reinterpret_cast<const int4*>(sh.ctl);
+    FusedCtl c;
+    c.converged = __builtin_amdgcn_readfirstlane(v.x); c.nev = __builtin_amdgcn_readfirstlane(v.y);
+    c.nslots = __builtin_amdgcn_readfirstlane(v.z); c.hashed = __builtin_amdgcn_readfirstlane(v.w);
+    return c;
+}
 
 template <typename R> struct Sig {   // per-signal views
     R* r; R* bc; int* bk;
@@ -809,6 +824,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
         sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1; sh.nullsel = 0; sh.hashed = 0; sh.fpos = 0;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
+        sh.ctl[0] = 0; sh.ctl[1] = sh.nev; sh.ctl[2] = sh.nslots; sh.ctl[3] = 0;
     }
     if constexpr (!Recorr::kFused) {
         for (int i = tid; i < (Recorr::kMaxSegments + 31) / 32; i += kThreads) sh.touched[i] = 0u;
@@ -835,10 +851,11 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     // several signals per workgroup: a signal's serial code outranks the other signals' tiles (hscmp_mfma.h, apply_atom)
     if constexpr (GS > 1) __builtin_amdgcn_s_setprio(3);
 
+    FusedCtl fc = fused_ctl_fetch(sh);                   // (behind the barrier above; only the fused bodies keep it current)
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         int nsel;
-        if constexpr (!Recorr::kFused) HSCMP_STAMP(39);
+        if constexpr (!Recorr::kFused) HSCMP_STAMP(39); else HSCMP_STAMP(10);     // fused: from the atom's return to the next round
         // =========================== select (modeling.py:899-982) ===========================
         int p_sel = 0, k_sel = 0;
         R c_sel = (R)0;
@@ -853,13 +870,19 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 // in index order, see wave_argmax_first -- and carries the position of its best.
                 Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
                 const int per = (P.nseg + 63) >> 6;
-                for (int j = 0; j < per; ++j) {                       // ascending i per lane: '>' keeps the first of equals
-                    const int i = lane * per + j;
-                    if (i < P.nseg) {
-                        const R sc = sh.seg_score[i];
-                        const int st = sh.seg_t[i];
-                        if (sc > c.s) { c.s = sc; c.i = st; }
+                for (int j0 = 0; j0 < per; j0 += 4) {                 // ascending i per lane: '>' keeps the first of equals
+                    // four maxima and their positions in ONE batch of LDS reads (clamped index, unconditional: a guarded
+                    // read per element compiles to a chain of dependent round trips)
+                    R sv[4]; int tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = min(lane * per + j0 + u, P.nseg - 1);
+                        sv[u] = sh.seg_score[i]; tv[u] = sh.seg_t[i];
                     }
+                    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < per && lane * per + j0 + u < P.nseg && sv[u] > c.s) { c.s = sv[u]; c.i = tv[u]; }
                 }
                 c = wave_argmax_first(c);
                 p_sel = c.i;
@@ -1031,10 +1054,12 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         if constexpr (!Recorr::kFused) HSCMP_STAMP(32);
         // A round whose atoms do not all fit the event list is not started: the state then is exactly that
         // of a round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
-        const bool lists_full = sh.nev + nsel > P.cap;  // uniform (LDS values after a barrier)
+        const int nev_now = Recorr::kFused ? fc.nev : sh.nev, nslots_now = Recorr::kFused ? fc.nslots : sh.nslots;
+        const bool hashed_now = Recorr::kFused ? fc.hashed != 0 : sh.hashed != 0;
+        const bool lists_full = nev_now + nsel > P.cap;  // uniform (LDS values after a barrier)
         // the slot list has outgrown the Bloom filter: duplicate lookups go through the hash table from here on
-        const bool build_table = !sh.hashed && sh.nslots >= P.hash_min;
-        const bool hashed = sh.hashed || build_table;
+        const bool build_table = !hashed_now && nslots_now >= P.hash_min;
+        const bool hashed = hashed_now || build_table;
         // every thread has read the event / slot counts before thread 0 advances them (the step-by-step body may
         // reach its bookkeeping without passing another barrier; the fused bodies pass several first)
         if constexpr (!Recorr::kFused) sy.full();
@@ -1046,7 +1071,8 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         if (build_table) {
             sy.full();                         // (drains the deferred slot stores of the fused bodies)
             slot_table_build(G, P.hmask, sh.nslots, sy);
-            if (tid == 0) sh.hashed = 1;
+            if (tid == 0) { sh.hashed = 1; sh.ctl[3] = 1; }
+            fc.hashed = 1;
             sy.full();
         }
         if constexpr (!Recorr::kFused) {
@@ -1070,7 +1096,10 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
             if constexpr (Recorr::kFused) {
                 // policy-owned atom body: one batch of global loads, LDS-only barriers (hscmp_mfma.h);
                 // in blocked mode (k, c) were resolved at selection time
-                if (Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0, sy)) { fused_stop = true; break; }
+                HSCMP_STAMP(11);                                   // selection + the round's checks
+                const bool stop_now = Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0, sy, fc);
+                HSCMP_STAMP(12);                                   // the atom body, entry checks included
+                if (stop_now) { fused_stop = true; break; }
                 continue;
             }
 
@@ -1243,7 +1272,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
             // single arg-max rounds without a residual-scale rule need no further synchronisation:
             // the stop decision already went through apply_atom's last barrier
             if (!P.blocked && !P.has_scale && nsel > 0) {
-                if (tid == 0) { sh.rounds += 1; sh.offset = !sh.offset; }
+                // (the round counter and the offset toggle of such a round are advanced by the atom body's bookkeeping)
                 if (fused_stop) break;
                 continue;
             }

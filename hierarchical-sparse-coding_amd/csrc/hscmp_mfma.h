@@ -871,8 +871,11 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     // Returns true when the atom loop must stop.
     template <typename SH>
     static __device__ __forceinline__ bool apply_atom(const DevParams& P, const State<R>& S, const Sig<R>& Gs,
-                                                      SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved, Sync& sy)
+                                                      SH& sh, const Args& A, char* lds, int p, int k, R c, bool resolved, Sync& sy,
+                                                      FusedCtl& fc)
     {
+        // single arg-max rounds without a residual-scale rule: the round's own bookkeeping (:1160-1163) is done here
+        const bool round_is_atom = !P.blocked && !P.has_scale;
         (void)S;
         // p (and k, c once known) are wave-uniform: telling the compiler moves the span / segment arithmetic that
         // derives from them to the scalar unit (the vector ALU is what the f32 MFMA competes for)
@@ -886,8 +889,8 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         const int T = P.T, W = P.W, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int S4 = S4C > 0 ? S4C : A.S4;
         const Layout L = layout(P, A, lds);
-        if (sh.nev >= P.cap) {                                  // event list full (uniform: LDS value)
-            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
+        if (fc.nev >= P.cap) {                                  // event list full
+            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; if (round_is_atom) { sh.rounds += 1; sh.offset = !sh.offset; } }
             sy.full();
             return true;
         }
@@ -974,7 +977,10 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
             c = wave_bcast(c, 0);
             if (P.has_thres && !(fabs((double)c) > P.thres)) {  // :974 null coefficient: empty selection
                 // (with a residual-scale rule the reference tests that rule first, :1145-1153: the slow rules name the reason)
-                if (tid == 0) { sh.converged = 1; sh.nullsel = 1; if (!P.has_scale && sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }
+                if (tid == 0) {
+                    sh.converged = 1; sh.nullsel = 1; if (!P.has_scale && sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY;
+                    if (round_is_atom) { sh.rounds += 1; sh.offset = !sh.offset; }
+                }
                 sy.full();
                 return true;
             }
@@ -985,7 +991,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         // duplicate check (:1106): Bloom filter in LDS; only a hit pays for the scan of the slot list
         // Long slot lists (sh.hashed, see slot_find): the bookkeeping thread probes the hash table instead; its
         // first probe is in flight under the atom's work and is only looked at in the bookkeeping below.
-        const bool hashed = sh.hashed != 0;                     // uniform: published before a full barrier
+        const bool hashed = fc.hashed != 0;                     // uniform: fetched behind the previous atom's last barrier
         const unsigned hb = bloom_hash(p, k);
         const bool maybe_dup = !hashed && ((L.bloom[hb >> 5] >> (hb & 31)) & 1u) != 0;      // uniform
         unsigned long long probe_key = kSlotEmpty;
@@ -1168,6 +1174,9 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
                 const R qv = sh.e_sig / sh.e_res;
                 if ((double)qv >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
             }
+            if (round_is_atom) { sh.rounds += 1; sh.offset = !sh.offset; }
+            // what the other waves need to know about this atom, in one 16-byte word (FusedCtl)
+            *reinterpret_cast<int4*>(sh.ctl) = make_int4(sh.converged, sh.nev, sh.nslots, hashed ? 1 : 0);
         }
         HSCMP_MARK("B5");
         HSCMP_STAMP(5);                                         // segment maxima + bookkeeping
@@ -1227,7 +1236,8 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         }
 #endif
         HSCMP_MARK("atom_end");
-        return sh.converged != 0;
+        fc = fused_ctl_fetch(sh);
+        return fc.converged != 0;
     }
 };
 

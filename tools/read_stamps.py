@@ -21,7 +21,7 @@ names = ['dup+update to B1', 'B1', 'energy', 'MFMA tile', 'B4', 'seg+bookkeeping
 print('B=%d atoms=%d loop %.3f ms' % (B, n, eng.last_kernel_ms()[2]))
 for i, nm in enumerate(names):
     print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
-for i, nm in ((8, 'phase A issue'), (9, 'resolve (Bx..By)')):
+for i, nm in ((8, 'phase A issue'), (9, 'resolve (Bx..By)'), (10, '[return -> next round]'), (11, '[selection + round checks]'), (12, '[atom body incl. entry]')):
     print('  %-18s %8.0f cycles/atom' % (nm, v[i] / n))
 print('  %-18s %8.0f cycles/atom (sum; the select between atoms is not stamped)' % ('total', (v[:8].sum() + v[8] + v[9]) / n))
 
