@@ -96,7 +96,7 @@ def load_library():
     lib.hscmp_assign_windows.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.hscmp_host_slots_to_csc.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_double, vp, vp, vp]
     lib.hscmp_host_overlap_add.argtypes = [vp, ctypes.c_int64, ci, vp, vp, vp, ctypes.c_int64, vp, ci, ci]
-    lib.hscmp_hierarchy_epilogue.argtypes = [vp, vp, ci, ctypes.POINTER(HscmpEpilogueLevel), ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp]
+    lib.hscmp_hierarchy_epilogue.argtypes = [vp, vp, ci, ctypes.POINTER(HscmpEpilogueLevel), ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.hscmp_encode_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_device.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HscmpParams)]
     lib.hscmp_encode_batch_from_level.argtypes = [vp, vp, ci, ci, ctypes.c_double, ctypes.POINTER(HscmpParams)]
@@ -364,9 +364,10 @@ class Engine(object):
         self._batch = (int(count), prev._batch[1], int(params.max_events))
 
     def hierarchy_epilogue(self, level0, first, levels, minCoefficients, slot_counts, want_events=True, want_residual=True,
-                           residual_out=None):
+                           residual_out=None, energy_out=None):
         """hscmp_hierarchy_epilogue on this (last-level) engine.  levels: list of (col0, col1, representations [K,scale(,Fd)]).
         slot_counts: int array [count], the slot count of every signal (stats[:, STAT_SLOTS]).
+        energy_out: float64 [count] array that receives the residual energies (sum of squares, summed on the device).
         Returns (n [count], colptr [count, K+1], offsets [count+1], indices, data, events or None, residual or None)."""
         count, T, _ = self._batch
         Fd = level0.F
@@ -396,9 +397,12 @@ class Engine(object):
             residual = residual_out
         else:
             residual = np.empty((count, T, Fd), dtype=np.float64) if want_residual else None
+        if energy_out is not None:
+            assert energy_out.shape == (count,) and energy_out.dtype == np.float64 and energy_out.flags.c_contiguous
         minc = float('nan') if minCoefficients is None else float(minCoefficients)
         self._check(self._lib.hscmp_hierarchy_epilogue(self._h, level0._h, int(first), arr, len(levels), ctypes.c_double(minc), _ptr(offsets),
-                                                       _ptr(n), _ptr(colptr), _ptr(indices), _ptr(data), _ptr(events), _ptr(residual)),
+                                                       _ptr(n), _ptr(colptr), _ptr(indices), _ptr(data), _ptr(events), _ptr(residual),
+                                                       _ptr(energy_out)),
                     'hscmp_hierarchy_epilogue')
         return n, colptr, offsets, indices, data, events, residual
 

@@ -80,7 +80,7 @@ struct hscmp_ctx {
     // device-resident inner-product table of LoCOMP (hscmp_table_*): [T][K] in slot kArenaTable, its residual in kArenaTabRes
     int tab_T = 0;
 };
-enum { kArenaRowA = 8, kArenaRowB = 9, kArenaRowC = 10, kArenaRowD = 11, kArenaTable = 12, kArenaTabRes = 13, kArenaTabW = 14 };
+enum { kArenaRowA = 8, kArenaRowB = 9, kArenaRowC = 10, kArenaRowD = 11, kArenaTable = 12, kArenaTabRes = 13, kArenaTabW = 14, kArenaEpiEnergy = 15 };
 
 static thread_local std::string g_err;
 
@@ -1034,7 +1034,8 @@ extern "C" int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slo
 
 extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int first, const hscmp_epilogue_level* levels, int nlevels,
                                         double min_coefficients, const int64_t* offsets, int32_t* out_n, int32_t* out_colptr,
-                                        int32_t* out_indices, double* out_data, void* out_events, double* out_residual)
+                                        int32_t* out_indices, double* out_data, void* out_events, double* out_residual,
+                                        double* out_residual_energy)
 {
     if (!last || !level0) return fail(last, HSCMP_ERR_INVALID, "hscmp_hierarchy_epilogue: NULL context");
     if (!last->have_batch || !level0->have_batch) return fail(last, HSCMP_ERR_STATE, "hscmp_hierarchy_epilogue: no batch encoded");
@@ -1094,6 +1095,11 @@ extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int 
     A.out_events = out_events ? (int*)last->d_epi[6] : nullptr;
     A.out_residual = out_residual ? (double*)((char*)last->d_epi[6] + (out_events ? ((size_t)total * 16 + 15) / 16 * 16 : 0)) : nullptr;
     A.scratch = (unsigned long long*)last->d_epi[7]; A.scratch_n = nmax;
+    A.out_energy = nullptr;
+    if (out_residual_energy) {
+        if ((rc = epi_buffer(last, kArenaEpiEnergy, (size_t)count * sizeof(double)))) return rc;
+        A.out_energy = (double*)last->d_epi[kArenaEpiEnergy];
+    }
     const size_t lds = (size_t)std::min(nmax, kEpiLdsKeys) * sizeof(unsigned long long);
     const size_t xoff = (size_t)first * T * Fd * esize(level0->dtype);
     if (level0->dtype == HSCMP_F32) {
@@ -1114,6 +1120,7 @@ extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int 
         if (out_events) HIP_TRY(last, hipMemcpyAsync(out_events, A.out_events, (size_t)total * 16, hipMemcpyDeviceToHost, last->stream));
     }
     if (out_residual) HIP_TRY(last, hipMemcpyAsync(out_residual, A.out_residual, nres, hipMemcpyDeviceToHost, last->stream));
+    if (out_residual_energy) HIP_TRY(last, hipMemcpyAsync(out_residual_energy, A.out_energy, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, last->stream));
     HIP_TRY(last, hipStreamSynchronize(last->stream));
     return HSCMP_OK;
 }

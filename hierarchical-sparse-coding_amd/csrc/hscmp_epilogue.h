@@ -15,6 +15,8 @@
 //   4. event records out
 //   5. per sample: the entries whose pattern covers it, level by level, each level in CSC order -- the order in which the
 //      reference's sequential overlap-add reaches that sample -- float64 sums: bit-identical to hscmp_host_overlap_add.
+//      Optionally the energy of the residual (sum of squares, fixed order) instead of / next to its samples: a caller that
+//      only checks the reconstruction quality need not move T samples per signal over PCIe.
 // Keys are 64-bit with the payload in the low bits (column 20 | t 24 | index 20), sorted in LDS when the list fits
 // (<= 16384 entries) and in a global scratch row otherwise.
 #pragma once
@@ -51,6 +53,7 @@ struct EpiArgs {
     int* out_indices; double* out_data;  // packed, CSC order
     int* out_events;                     // packed 16-byte records (t, level, index, float value), or nullptr
     double* out_residual;                // [count][T][Fd] or nullptr
+    double* out_energy;                  // [count] sum of the squared residual samples, or nullptr
     unsigned long long* scratch;         // [count][scratch_n] keys of lists that do not fit LDS
     int scratch_n;
 };
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_kept;
+    __shared__ double s_energy[kEpiThreads / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nslots = A.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
     int N = 2;
@@ -157,11 +161,12 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
     }
 
     // ---- 5. residual: x - sum over the levels of their synthesis, each level's terms in CSC order
-    if (A.out_residual) {
+    if (A.out_residual || A.out_energy) {
         const int64_t nel = (int64_t)A.T * A.Fd;
         const XR* xb = x + (int64_t)b * nel;
-        double* rb = A.out_residual + (int64_t)b * nel;
+        double* rb = A.out_residual ? A.out_residual + (int64_t)b * nel : nullptr;
         const double* data = A.out_data + off;
+        double esum = 0.0;                                   // this thread's samples, in index order
         for (int64_t e = tid; e < nel; e += kEpiThreads) {
             const int s = (int)(e / A.Fd), fd = (int)(e - (int64_t)s * A.Fd);
             // first entry with t >= s - max_back (binary search over the t-sorted keys)
@@ -202,7 +207,21 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
                 }
                 recon = recon + sig;                                             // reconstruction += reconstructSignal(level), :1606-1608
             }
-            rb[e] = (double)xb[e] - recon;
+            const double rv = (double)xb[e] - recon;
+            if (rb) rb[e] = rv;
+            esum = esum + rv * rv;
+        }
+        if (A.out_energy) {
+            // fixed summation order: per thread over its strided samples, xor tree inside the wave, the 16 wave sums in order
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) esum = esum + __shfl_xor(esum, m);
+            if ((tid & 63) == 0) s_energy[tid >> 6] = esum;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < kEpiThreads / 64; ++w) tot = tot + s_energy[w];
+                A.out_energy[b] = tot;
+            }
         }
     }
 }

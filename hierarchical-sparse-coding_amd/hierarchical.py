@@ -143,7 +143,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
                                  returnDistributed=True, chained=True, memoryBudget=None, epilogue='device', returnEvents=False,
-                                 deviceInput=None):
+                                 deviceInput=None, residuals='samples'):
         """Batch form (the reference has no batch axis): `sequences` [B,T] (or [B,T,F]); every level encodes
         many signals per GPU call.  chained=True keeps the level hand-off on the device
         (hscmp_encode_batch_from_level): the dense [T, K_prev] float64 input of a level (modeling.py:1489)
@@ -156,8 +156,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         are fetched once; 'host' assembles them signal by signal on the CPU (same results bit for bit).
         deviceInput: device address of `sequences` ([B,T,F] in the level-0 compute dtype) when they already sit in GPU
         memory (chained only); the host array is then used for its shape and dtype only.
+        residuals='energy' (device epilogue only): the second item returned is the float64 vector [B] of residual energies
+        (sum of squares, summed on the device); the residual samples -- T float64 per signal -- never cross PCIe.
         Returns (per-signal lists of per-level coefficient matrices, residuals [B,T(,F)] float64,
         per-level kernel timings); with returnEvents=True a fourth item: per-signal event record arrays."""
+        assert residuals in ('samples', 'energy')
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
             # LoCOMP is a host-driven loop around the GPU hooks: signal by signal
@@ -179,6 +182,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             return D, weights, targetSnr, float(np.finfo(D.dtype).eps)
 
         device_epilogue = chained and epilogue == 'device'
+        assert residuals == 'samples' or device_epilogue, "residuals='energy' needs the device epilogue"
 
         def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
@@ -254,7 +258,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             per_signal = sum(1.05 * T * setups[l][0].shape[2] * 8 + 160 * T + 80.0 * max(4096, 2 * nin0) for l in range(1, nbLevels))
             chunk = int(max(1, min(B, memoryBudget // max(per_signal, 1.0)))) if nbLevels > 1 else B
             results = [None] * B
-            residual_all = np.empty((B, T, x.shape[2]), dtype=np.float64) if device_epilogue else None
+            residual_all = np.empty((B, T, x.shape[2]), dtype=np.float64) if (device_epilogue and residuals == 'samples') else None
+            energy_all = np.empty((B,), dtype=np.float64) if (device_epilogue and residuals == 'energy') else None
             first = 0
             while first < B and (nbLevels > 1 or device_epilogue):
                 count = min(chunk, B - first)
@@ -281,11 +286,15 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 if device_epilogue:
                     slot_counts = (stats0 if nbLevels == 1 else last_stats)[(first if nbLevels == 1 else 0):(first if nbLevels == 1 else 0) + count, _native.STAT_SLOTS]
                     self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents,
-                                          residual_all[first:first + count])
+                                          None if residual_all is None else residual_all[first:first + count],
+                                          None if energy_all is None else energy_all[first:first + count])
                 first += count
             if device_epilogue:
-                residuals = residual_all[:, :, 0] if np.asarray(sequences).ndim == 2 else residual_all
-                out = ([r[0] for r in results], residuals, timings)
+                if energy_all is not None:
+                    second = energy_all
+                else:
+                    second = residual_all[:, :, 0] if np.asarray(sequences).ndim == 2 else residual_all
+                out = ([r[0] for r in results], second, timings)
                 return out + ([r[2] for r in results],) if returnEvents else out
 
         # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
@@ -309,7 +318,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             out = out + ([convertSparseMatricesToEvents(c) for c in coefficients],)
         return out
 
-    def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents, residual_out):
+    def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents, residual_out,
+                         energy_out=None):
         """hscmp_hierarchy_epilogue for one chunk: per signal the per-level coefficient matrices (:1556-1634), the residual
         (:1596-1611) and the event records (dataset.py:798-811), from the last level's device-resident slots."""
         import scipy.sparse
@@ -324,8 +334,9 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             else:
                 levels.append((0, counts[l], reps[l]) if l == nbLevels - 1 else (0, 0, None))
         n, colptr, offsets, indices, data, events, residual = last.hierarchy_epilogue(
-            engines[0], first if nbLevels > 1 else 0, levels, 1e-16, slot_counts, want_events=returnEvents, residual_out=residual_out)
-        T = residual.shape[1]
+            engines[0], first if nbLevels > 1 else 0, levels, 1e-16, slot_counts, want_events=returnEvents, want_residual=residual_out is not None,
+            residual_out=residual_out, energy_out=energy_out)
+        T = last._batch[1]
         # per-level column pointers of the whole chunk at once: level l is the slice [c0, c1) of the last level's columns
         ptrs, starts = [], []
         for l, (c0, c1, _) in enumerate(levels):
@@ -344,7 +355,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     mats.append(scipy.sparse.csc_matrix((T, counts[l]), dtype=np.float64))
                     continue
                 lo = o + int(starts[l][b]); hi = lo + int(ptrs[l][b, -1])
-                mats.append(scipy.sparse.csc_matrix((data[lo:hi], indices[lo:hi], ptrs[l][b]), shape=(T, counts[l]), copy=False))
+                mats.append(_csc_from_checked_arrays(data[lo:hi], indices[lo:hi], ptrs[l][b], (T, counts[l])))
             ev = events[o:o + int(n[b])] if events is not None else None
             results[first + b] = (mats, None, ev)
 
@@ -357,6 +368,26 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         coefficients = self._forwardPhaseFromLevel(sequence, coefficients, multilevelDict, toleranceSnr, nbBlocks,
                                                    singletonWeight, stopCondition)
         return self._postprocessCoefficients(coefficients, multilevelDict, returnDistributed)
+
+
+def _csc_from_checked_arrays(data, indices, indptr, shape):
+    """csc_matrix over arrays the device epilogue wrote (canonical: int32 indices sorted inside every column, no
+    duplicates, no zeros).  The public constructor re-validates and re-derives the index dtype -- 18 us per matrix,
+    36 ms for the 2048 matrices of a config-4 batch; a matrix whose attributes are set directly is the same object
+    to every consumer.  Falls back to the constructor if this scipy lays the object out differently."""
+    import scipy.sparse
+    try:
+        m = scipy.sparse.csc_matrix.__new__(scipy.sparse.csc_matrix)
+        m.data, m.indices, m.indptr = data, indices, indptr
+        m._shape = (int(shape[0]), int(shape[1]))
+        m.maxprint = 50
+        m.has_sorted_indices = True
+        m.has_canonical_format = True
+        if m.shape != m._shape or m.nnz != len(data):
+            raise AttributeError
+        return m
+    except Exception:
+        return scipy.sparse.csc_matrix((data, indices, indptr), shape=shape, copy=False)
 
 
 class HierarchicalConvolutionalSparseCoder(object):

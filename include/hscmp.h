@@ -187,7 +187,10 @@ int hscmp_host_slots_to_csc(const int32_t* slot_t, const int32_t* slot_k, const 
  *     then level, then index (out_events may be NULL);
  *   - the residual of modeling.py:1596-1611, x - sum_l reconstructSignal(level l, levels[l].rep) in float64, every sum
  *     in the order of the reference's sequential overlap-add (bit-identical to hscmp_host_overlap_add level by level;
- *     out_residual [count][T][Fd] may be NULL).
+ *     out_residual [count][T][Fd] may be NULL);
+ *   - out_residual_energy [count] (may be NULL): the sum of the squared residual samples of every signal, summed on the
+ *     device in a fixed order -- what a caller that only checks the reconstruction quality (10 log10(E_x / E_r)) needs,
+ *     without moving T samples per signal over PCIe.
  * levels[l].rep: host pointer to the input-level patterns [>= col1][scale][Fd] of level l (getMultiscaleDictionaries),
  * float32 (rep_is_f32 != 0) or float64.  offsets [count + 1] (host): entry offset of every signal in the packed outputs
  * out_indices / out_data / out_events (offsets[b + 1] - offsets[b] >= that signal's slot count); out_n [count] receives
@@ -200,7 +203,8 @@ typedef struct hscmp_epilogue_level {
 } hscmp_epilogue_level;
 int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int first, const hscmp_epilogue_level* levels, int nlevels,
                              double min_coefficients, const int64_t* offsets, int32_t* out_n, int32_t* out_colptr,
-                             int32_t* out_indices, double* out_data, void* out_events, double* out_residual);
+                             int32_t* out_indices, double* out_data, void* out_events, double* out_residual,
+                             double* out_residual_energy);
 
 /* Run up to max_rounds further selection rounds on the signals that have not converged
  * (modeling.py:1086 loop); used by hosts that evaluate a stopCondition callback (:1155-1158)

@@ -63,8 +63,8 @@ lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
 assert lib.hscmp_fetch_events(null, buf, buf, buf) != 0
 lib.hscmp_fetch_slots.argtypes = [vp, vp, vp, vp]
 assert lib.hscmp_fetch_slots(null, buf, buf, buf) != 0
-lib.hscmp_hierarchy_epilogue.argtypes = [vp, vp, ci, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp]
-assert lib.hscmp_hierarchy_epilogue(null, null, 0, buf, 1, 0.0, buf, buf, buf, buf, buf, None, None) != 0
+lib.hscmp_hierarchy_epilogue.argtypes = [vp, vp, ci, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
+assert lib.hscmp_hierarchy_epilogue(null, null, 0, buf, 1, 0.0, buf, buf, buf, buf, buf, None, None, None) != 0
 lib.hscmp_synchronize.argtypes = [vp]
 assert lib.hscmp_synchronize(null) != 0
 lib.hscmp_set_stream.argtypes = [vp, vp]

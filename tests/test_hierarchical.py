@@ -283,6 +283,14 @@ def test_device_epilogue_equals_host_epilogue(distributed):
                 assert np.array_equal(a.indptr, h.indptr) and np.array_equal(a.indices, h.indices) and np.array_equal(a.data, h.data)
             assert ed[b].dtype == eh[b].dtype and np.array_equal(ed[b], eh[b]), b
             assert np.array_equal(ed[b], convertSparseMatricesToEvents(cd[b]))
+        # residuals='energy': the same coefficients, and the energies of those residuals (summed on the device) instead of
+        # their samples
+        ce, en, _ = hcmp.computeCoefficientsBatch(xs, mld, memoryBudget=budget, epilogue='device', residuals='energy', **kw)
+        assert en.shape == (xs.shape[0],) and en.dtype == np.float64
+        assert np.allclose(en, np.sum(np.square(rd.reshape((xs.shape[0], -1))), axis=1), rtol=1e-12, atol=0.0)
+        for b in range(xs.shape[0]):
+            for l in range(3):
+                assert (scipy.sparse.csc_matrix(ce[b][l]) != scipy.sparse.csc_matrix(cd[b][l])).nnz == 0, (b, l)
     hcmp.close()
 
 
