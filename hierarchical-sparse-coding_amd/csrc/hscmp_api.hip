@@ -500,7 +500,7 @@ template <typename R, bool PACKED> static int launch_iterate_sparse_t(hscmp_ctx*
     if (lds_out) *lds_out = lds;
     if (dry) return HSCMP_OK;
     auto kern = iterate_kernel<R, Pol>;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
 }
@@ -519,7 +519,7 @@ template <typename R> static int launch_corr_init_sparse(hscmp_ctx* ctx, const D
     const SparseArgs<R> A = sparse_args<R>(ctx, P.T);
     const size_t lds = sparse_lds_bytes<R>(A.caps) + staged_dict_bytes(P, A) + (size_t)((P.T + 31) / 32) * sizeof(unsigned);
     auto kern = corr_init_sparse_kernel<R>;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(P.B, sparse_init_split(P.B, P.T, P.W)), dim3(kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
 }
@@ -531,7 +531,7 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
     set_segments(P, GenericRecorr<R>::kMaxSegments);
     const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
     auto kern = iterate_kernel<R, GenericRecorr<R>>;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
     return HSCMP_OK;
 }
@@ -1104,11 +1104,11 @@ extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int 
     const size_t xoff = (size_t)first * T * Fd * esize(level0->dtype);
     if (level0->dtype == HSCMP_F32) {
         auto kern = hier_epilogue_kernel<float>;
-        HIP_TRY(last, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(last, set_dyn_lds((const void*)kern, lds));
         hipLaunchKernelGGL(kern, dim3(count), dim3(kEpiThreads), lds, last->stream, A, (const float*)((const char*)level0->last_x_dev + xoff));
     } else {
         auto kern = hier_epilogue_kernel<double>;
-        HIP_TRY(last, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(last, set_dyn_lds((const void*)kern, lds));
         hipLaunchKernelGGL(kern, dim3(count), dim3(kEpiThreads), lds, last->stream, A, (const double*)((const char*)level0->last_x_dev + xoff));
     }
     HIP_TRY(last, hipGetLastError());
@@ -1173,7 +1173,7 @@ static int select_on_device(hscmp_ctx* ctx, const R* d_ip, const R* d_w, int T, 
     set_segments(P, GenericRecorr<R>::kMaxSegments);
     const size_t lds = ((sizeof(typename GenericRecorr<R>::Shared) + 15) / 16) * 16 + GenericRecorr<R>::extra_lds_bytes(P);
     auto kern = iterate_kernel<R, GenericRecorr<R>>;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(kThreads), lds, ctx->stream, P, S, typename GenericRecorr<R>::Args{});
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));

@@ -9,6 +9,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <map>
+#include <tuple>
+#include <utility>
 #include <stdint.h>
 #include <limits.h>
 
@@ -198,6 +201,35 @@ inline void set_segments(DevParams& P, int maxseg)
     P.seg = seg;
     P.seg_shift = shift;
     P.nseg = (P.T + seg - 1) / seg;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) raises a ceiling: once a kernel has been allowed `lds` bytes on a device
+// every smaller request is covered.  The call takes the host some tens of microseconds and used to sit between two
+// queued kernels of every encode (a gap on the GPU whenever the host is not ahead of it), as did the occupancy query of
+// the persistent initial correlation: both are answered from a per-thread cache after the first time.
+inline hipError_t set_dyn_lds(const void* kern, size_t lds)
+{
+    static thread_local std::map<std::pair<int, const void*>, size_t> allowed;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    size_t& have = allowed[std::make_pair(dev, kern)];
+    if (have >= lds && have > 0) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
+}
+inline int cached_blocks_per_cu(const void* kern, int threads, size_t lds)
+{
+    static thread_local std::map<std::tuple<int, const void*, int, size_t>, int> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    auto key = std::make_tuple(dev, kern, threads, lds);
+    auto it = seen.find(key);
+    if (it != seen.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    seen[key] = per_cu;
+    return per_cu;
 }
 
 enum { ST_NNZ = 0, ST_DUP = 1, ST_ROUNDS = 2, ST_STOP = 3, ST_ITERS = 4, ST_EVENTS = 5, ST_SLOTS = 6,

@@ -1262,12 +1262,11 @@ static int mfma_launch_corr_init_t(hipStream_t stream, const DevParams& P, const
     using R = typename Tile::R;
     const size_t lds = ((size_t)A.G * A.S4 * Tile::kChunkElems + Tile::GA * A.G + kMfmaChunk + 8 * A.S4 + 32) * sizeof(R);
     auto kern = corr_init_mfma_kernel<Tile, S4C, HAS_W>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (set_dyn_lds((const void*)kern, lds) != hipSuccess) return -1;
     if (dry) return 0;
     // persistent grid: as many workgroups as are resident at once (LDS-bound), capped by the work
     const int cus = mfma_device_cus();
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int per_cu = cached_blocks_per_cu((const void*)kern, kThreads, lds);
     const int64_t nitems = (int64_t)((P.T + kMfmaChunk - 1) / kMfmaChunk) * P.B;
     int64_t grid = (int64_t)cus * per_cu;
     if (const char* e = getenv("HSCMP_INIT_PER_CU")) grid = (int64_t)cus * std::max(1, atoi(e));      // diagnostic: fewer resident workgroups
@@ -1290,7 +1289,7 @@ static int mfma_launch_iterate_g(hipStream_t stream, const DevParams& P0, const 
     if (GS > 1 && lds > (size_t)160 * 1024) return -1;
     if (const char* pad = getenv("HSCMP_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: force a lower occupancy
     auto kern = iterate_kernel<typename Tile::R, Pol>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (set_dyn_lds((const void*)kern, lds) != hipSuccess) return -1;
     if (dry) return 0;
     if (getenv("HSCMP_DEBUG")) {
         int per_cu = -1;
