@@ -172,6 +172,11 @@ class DeviceTable(object):
         self.shape = (T, engine.K)
         self.dtype = engine.dtype
         self._pending = None              # (lo, hi, residual, [centres]): updates not yet sent to the device
+        self._generation = engine._table_generation      # the engine holds ONE table: a later table_open retires this handle
+
+    def _check_current(self):
+        if self._generation != self.engine._table_generation:
+            raise HscmpError('this DeviceTable was replaced by a later table_open on the same engine')
 
     def defer_update(self, residual, lo, hi, centres):
         """Record an update (residual samples [lo, hi) changed, rows around `centres` to be re-correlated).  Nothing
@@ -187,6 +192,7 @@ class DeviceTable(object):
             self._pending[3].extend(centres)
 
     def flush(self):
+        self._check_current()
         if self._pending is not None:
             lo, hi, residual, centres = self._pending
             self._pending = None
@@ -311,6 +317,7 @@ class Engine(object):
         assert r.shape[1] == self.F
         self._check(self._lib.hscmp_table_open(self._h, _ptr(r), r.shape[0]), 'hscmp_table_open')
         self._table_T = r.shape[0]
+        self._table_generation = getattr(self, '_table_generation', 0) + 1
         return DeviceTable(self, r.shape[0])
 
     def table_select(self, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):

@@ -149,6 +149,10 @@ def test_table_calls_without_open_table_fail_loudly():
         eng.table_update(np.zeros((4, 1), dtype=np.float32), 14, [3])       # samples past the end
     with pytest.raises(_native.HscmpError):
         eng.table_update(np.zeros((4, 1), dtype=np.float32), 0, [16])       # centre outside the signal
+    tab2 = eng.table_open(np.ones((16, 1), dtype=np.float32))               # the engine holds one table: the old handle is retired
+    with pytest.raises(_native.HscmpError):
+        tab.flush()
+    tab = tab2
     eng.set_dictionary(2 * D)                                               # a new dictionary drops the table
     with pytest.raises(_native.HscmpError):
         tab.read()
