@@ -233,3 +233,53 @@ def test_config4_consistent_hierarchy_reconstructs():
     assert np.all(snr >= 25.0), snr.min()
     assert sum(c[1][:, 256:].nnz for c in coefs) > 10 * B        # composite atoms are actually used
     gpu.close()
+
+
+@pytest.mark.gpu
+def test_config5_generated_three_level_dictionary(monkeypatch):
+    """BASELINE configs[4] at its dictionary dimensions: generated Perlin dictionary, scales [32, 64, 128] (taps 32 / 33 /
+    65), 4x overcomplete per level plus singleton bases => level dictionaries 128x32, (128+132)x33x128, (260+260)x65x260;
+    Poisson-event signals at compression 0.25 (bench_hsc.build_workload).  24 signals of 8192 samples through the
+    device-chained batch path: two of them against the host logic with the CPU oracle as level coder, bit for bit on all
+    three levels; all of them against the per-signal path property (batch == single) on a sample, the independent
+    reconstruction check, and a second run."""
+    import bench_hsc
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    B, T = 24, 8192
+    mlds, xs, kw, _ = bench_hsc.build_workload(5, B, T, 0)
+    assert [tuple(mlds.getRawDictionary(l).shape) for l in range(3)] == [(128, 32), (260, 33, 128), (520, 65, 260)]
+    gpu = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    coefs, residuals, timings = gpu.computeCoefficientsBatch(xs, mlds, **kw)
+    assert timings[0]['variant'].startswith('mfma_init+mfma_loop') and all(t['variant'].startswith('dictlist_init+dictlist_loop') for t in timings[1:])
+    ref = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    monkeypatch.setattr(ref, '_level_coder', lambda D: _OracleLevelCoder(D))
+    for b in (0, 17):
+        exp_c, exp_r = ref.computeCoefficients(xs[b], mlds, **kw)
+        for l in range(3):
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (b, l)
+        assert np.array_equal(residuals[b], exp_r), b
+    for b in (5, 23):
+        c1, r1 = gpu.computeCoefficients(xs[b], mlds, **kw)
+        for l in range(3):
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(c1[l])).nnz == 0, (b, l)
+        assert np.array_equal(residuals[b], r1), b
+    reps = mlds.getMultiscaleDictionaries()
+    snr = []
+    for b in range(B):
+        recon = np.zeros(T)
+        for l in range(3):
+            m = scipy.sparse.coo_matrix(coefs[b][l])
+            sc = reps[l].shape[1]
+            for t, k, c in zip(m.row, m.col, m.data):
+                lo = t - (sc - 1) // 2
+                s, e = max(lo, 0), min(lo + sc, T)
+                recon[s:e] += c * reps[l][k][s - lo:e - lo].astype(np.float64)
+        assert float(np.max(np.abs((xs[b] - recon) - residuals[b]))) <= 1e-9, b
+        snr.append(10 * np.log10(np.sum(xs[b].astype(np.float64) ** 2) / np.sum(residuals[b] ** 2)))
+    assert min(snr) >= 20.0, min(snr)
+    coefs2, residuals2, _ = gpu.computeCoefficientsBatch(xs, mlds, **kw)
+    assert np.array_equal(residuals, residuals2)
+    for b in range(B):
+        for l in range(3):
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs2[b][l])).nnz == 0, (b, l)
+    gpu.close()
