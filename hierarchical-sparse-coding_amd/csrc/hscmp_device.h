@@ -98,6 +98,16 @@ __device__ __forceinline__ int gsig()
 #endif
 }
 
+// threadIdx.x the compiler cannot see through: what is derived from it inside a per-atom function is recomputed there
+// instead of being hoisted out of the atom loop (where it would be live across everything and, in the 128-VGPR builds,
+// spilled -- every reload a memory round trip on a latency-bound path)
+__device__ __forceinline__ int laundered_tid()
+{
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 struct HwSync {
     static constexpr int kGroup = 1;
     __device__ __forceinline__ void lds() { lds_barrier(); }

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     char* sbase = smem + Recorr::signal_lds_offset(P, A);
     SH& sh = *reinterpret_cast<SH*>(sbase);
     char* plds = sbase + ((sizeof(SH) + 15) / 16) * 16;
-    const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
+    int tid = ltid(), lane = tid & 63, wv = tid >> 6;     // (re-derived at the top of every round: see laundered_tid)
     typename Recorr::Sync sy = Recorr::make_sync(sh);
     int* stats = S.stats + (int64_t)b * ST_COUNT;
     if (stats[ST_STOP] != STOP_RUNNING) return;          // converged in an earlier launch
@@ -854,6 +854,8 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     FusedCtl fc = fused_ctl_fetch(sh);                   // (behind the barrier above; only the fused bodies keep it current)
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wv = tid >> 6;
         int nsel;
         if constexpr (!Recorr::kFused) HSCMP_STAMP(39); else HSCMP_STAMP(10);     // fused: from the atom's return to the next round
         // =========================== select (modeling.py:899-982) ===========================

@@ -222,7 +222,7 @@ template <typename R>
 __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G, const SparseArgs<R>& A, const SparseLds<R>& L,
                                              const unsigned* rowbits, int g0, int nwin, bool reflect, int sidx, int nslice)
 {
-    const int T = P.T, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int T = P.T, F = P.F, tid = laundered_tid(), lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, rowcap = L.caps.rows;
     if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
     __syncthreads();
@@ -348,7 +348,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
                                             const SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
                                             int sidx, int nslice, bool gathered = false)
 {
-    const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int T = P.T, K = P.K, W = P.W, F = P.F, tid = laundered_tid(), lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, reccap = L.caps.rec;
     R* tab = A.scratch + (int64_t)blockIdx.x * (2 * W - 1) * K;
     const int nwin = nrows + W - 1;                 // residual rows the block can see
@@ -684,7 +684,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     static __device__ __forceinline__ bool merged_update(const DevParams& P, const Sig<R>& G, const Args& A, const SparseLds<R>& L,
                                                          int p, int k, R c, int s, int e, R& pb, R& pa)
     {
-        const int T = P.T, F = P.F, W = P.W, tid = threadIdx.x;
+        const int T = P.T, F = P.F, W = P.W, tid = laundered_tid();
         const int g0 = p - P.off - (W - 1), nwin = 3 * W - 2;
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * 8;
@@ -823,7 +823,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
         if (!A0.rl_cnt) return false;
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
-        const int T = P.T, F = P.F, tid = threadIdx.x, C = A.rl_cap, shift = __ffs(C) - 1;
+        const int T = P.T, F = P.F, tid = laundered_tid(), C = A.rl_cap, shift = __ffs(C) - 1;
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
         {
@@ -988,7 +988,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     {
         if (!A0.rl_cnt) return false;
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
-        const int T = P.T, F = P.F, tid = threadIdx.x, C = A0.rl_cap, shift = __ffs(C) - 1;
+        const int T = P.T, F = P.F, tid = laundered_tid(), C = A0.rl_cap, shift = __ffs(C) - 1;
         const int* cnt = A0.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A0.rl_f + (int64_t)blockIdx.x * T * C;
         int* key = L.key; R* val = L.val; int* order = L.perm;
