@@ -727,6 +727,8 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
 
     static __host__ __device__ int window_floats(int W, int S4) { return ((2 * W - 1 + TP - 1) / TP) * TP + 8 * S4 + 32; }
     static __host__ __device__ int segbuf_len(int W, int seg) { return ((2 * W - 2) / seg + 2) * seg; }
+    // (the same with the segment length as a shift: P.seg == 1 << P.seg_shift -- no integer division on the device)
+    static __host__ __device__ int segbuf_len_p(const DevParams& P) { return (((2 * P.W - 2) >> P.seg_shift) + 2) << P.seg_shift; }
     // LDS: what the signals of a workgroup share (dictionary image, weights), then per signal the control block and
     // its windows.  GS == 1: [control][image | weights | windows ...] as one region behind the control block.
     static __host__ __device__ size_t shared_lds_bytes(const Args& A)
@@ -735,7 +737,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     }
     static __host__ __device__ size_t private_lds_bytes(const DevParams& P, const Args& A)
     {
-        const size_t relems = (size_t)window_floats(P.W, A.S4) + 2 * 8 * A.S4 + (size_t)segbuf_len(P.W, P.seg) + 8 * A.S4 + kWaves * 8 * A.S4;
+        const size_t relems = (size_t)window_floats(P.W, A.S4) + 2 * 8 * A.S4 + (size_t)segbuf_len_p(P) + 8 * A.S4 + kWaves * 8 * A.S4;
         return relems * sizeof(R) + kBloomWords * sizeof(unsigned) + kEdgeWords * sizeof(unsigned long long);
     }
     static __host__ __device__ size_t per_signal_lds_bytes(const DevParams& P, const Args& A)
@@ -763,7 +765,7 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         L.wts = L.dimg + A.G * S4 * Tile::kChunkElems;
         L.nwin = window_floats(P.W, S4);
         L.wp = 8 * S4;
-        L.nsbmax = __builtin_amdgcn_readfirstlane(segbuf_len(P.W, P.seg));      // (integer division: see signal_lds_offset)
+        L.nsbmax = segbuf_len_p(P);
         L.win = GS == 1 ? L.wts + (HAS_W ? Tile::GA * A.G : 0) : reinterpret_cast<R*>(lds);
         L.esq = L.win + L.nwin;
         L.sbs = L.esq + 2 * L.wp;
