@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libhscmp.so')
+# (HSCMP_LIBRARY: another build of the same ABI, for A/B timing of diagnostic builds -- tools/time_lib.py)
+LIB_PATH = os.environ.get('HSCMP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libhscmp.so')
 
 F32, F64 = 0, 1
 STAT_NNZ, STAT_DUPLICATES, STAT_ROUNDS, STAT_STOP, STAT_ITERATIONS, STAT_EVENTS, STAT_SLOTS, STAT_OFFSET = range(8)

@@ -101,10 +101,12 @@ __device__ __forceinline__ int gsig()
 // threadIdx.x the compiler cannot see through: what is derived from it inside a per-atom function is recomputed there
 // instead of being hoisted out of the atom loop (where it would be live across everything and, in the 128-VGPR builds,
 // spilled -- every reload a memory round trip on a latency-bound path)
-__device__ __forceinline__ int laundered_tid()
+// (ON only in the builds that are short of registers: where there is room the hoisted values cost nothing and the
+// recomputation does -- measured 2 % on the roomy level loop)
+template <bool ON> __device__ __forceinline__ int laundered_tid()
 {
     int t = (int)threadIdx.x;
-    asm volatile("" : "+v"(t));
+    if constexpr (ON) asm volatile("" : "+v"(t));
     return t;
 }
 

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     FusedCtl fc = fused_ctl_fetch(sh);                   // (behind the barrier above; only the fused bodies keep it current)
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
-        asm volatile("" : "+v"(tid));
+        if constexpr (Recorr::kMinWavesPerSimd >= 4) asm volatile("" : "+v"(tid));     // (register-constrained builds only)
         lane = tid & 63; wv = tid >> 6;
         int nsel;
         if constexpr (!Recorr::kFused) HSCMP_STAMP(39); else HSCMP_STAMP(10);     // fused: from the atom's return to the next round

@@ -218,11 +218,11 @@ __device__ __forceinline__ int list_count(const int* p)
 // order.  With per-row feature lists (A.rl_cnt) only the listed cells are read; otherwise rows are scanned,
 // and with rowbits (LDS, may be nullptr) only those whose bit is set.  Returns the number
 // of non-zeros found (> caps.nz: the list overflowed and is unusable).  Contains barriers.
-template <typename R>
+template <typename R, bool LAUNDER = false>
 __device__ __forceinline__ int gather_window(const DevParams& P, const Sig<R>& G, const SparseArgs<R>& A, const SparseLds<R>& L,
                                              const unsigned* rowbits, int g0, int nwin, bool reflect, int sidx, int nslice)
 {
-    const int T = P.T, F = P.F, tid = laundered_tid(), lane = tid & 63, wv = tid >> 6;
+    const int T = P.T, F = P.F, tid = laundered_tid<LAUNDER>(), lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, rowcap = L.caps.rows;
     if (tid == 0) { L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
     __syncthreads();
@@ -343,12 +343,12 @@ __device__ __forceinline__ unsigned long long score_bits(float s) { return (unsi
 
 // Rows [row0, row0+nrows) x all atoms -> per-position best (best_c, best_k), sparsity aware.
 //   nrows <= 2W-1 (table capacity).  All threads of the workgroup call it (contains barriers).
-template <typename R>
+template <typename R, bool LAUNDER = false>
 __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& S, const Sig<R>& G, const SparseArgs<R>& A,
                                             const SparseLds<R>& L, const unsigned* rowbits, int row0, int nrows, bool reflect,
                                             int sidx, int nslice, bool gathered = false)
 {
-    const int T = P.T, K = P.K, W = P.W, F = P.F, tid = laundered_tid(), lane = tid & 63, wv = tid >> 6;
+    const int T = P.T, K = P.K, W = P.W, F = P.F, tid = laundered_tid<LAUNDER>(), lane = tid & 63, wv = tid >> 6;
     const int nzcap = L.caps.nz, reccap = L.caps.rec;
     R* tab = A.scratch + (int64_t)blockIdx.x * (2 * W - 1) * K;
     const int nwin = nrows + W - 1;                 // residual rows the block can see
@@ -364,7 +364,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
         if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
         lds_barrier();
     } else {
-        n = gather_window(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
+        n = gather_window<R, LAUNDER>(P, G, A, L, rowbits, g0, nwin, reflect, sidx, nslice);
     }
     HSCMP_STAMP(40);
     HSCMP_TALLY(0, 1); HSCMP_TALLY(1, n); HSCMP_TALLY(2, n > nzcap); HSCMP_TALLY(5, L.ctl[1]);
@@ -684,7 +684,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     static __device__ __forceinline__ bool merged_update(const DevParams& P, const Sig<R>& G, const Args& A, const SparseLds<R>& L,
                                                          int p, int k, R c, int s, int e, R& pb, R& pa)
     {
-        const int T = P.T, F = P.F, W = P.W, tid = laundered_tid();
+        const int T = P.T, F = P.F, W = P.W, tid = laundered_tid<PACKED>();
         const int g0 = p - P.off - (W - 1), nwin = 3 * W - 2;
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * 8;
@@ -823,7 +823,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
         if (!A0.rl_cnt) return false;
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
-        const int T = P.T, F = P.F, tid = laundered_tid(), C = A.rl_cap, shift = __ffs(C) - 1;
+        const int T = P.T, F = P.F, tid = laundered_tid<PACKED>(), C = A.rl_cap, shift = __ffs(C) - 1;
         const int* cnt = A.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A.rl_f + (int64_t)blockIdx.x * T * C;
         {
@@ -988,7 +988,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     {
         if (!A0.rl_cnt) return false;
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
-        const int T = P.T, F = P.F, tid = laundered_tid(), C = A0.rl_cap, shift = __ffs(C) - 1;
+        const int T = P.T, F = P.F, tid = laundered_tid<PACKED>(), C = A0.rl_cap, shift = __ffs(C) - 1;
         const int* cnt = A0.rl_cnt + (int64_t)blockIdx.x * T;
         const int* lf = A0.rl_f + (int64_t)blockIdx.x * T * C;
         int* key = L.key; R* val = L.val; int* order = L.perm;
@@ -1121,7 +1121,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
         const int eidx = tend > T - 1 ? T - 1 : tend;      // :1039
         HSCMP_STAMP(45);
         const bool gathered = A.rl_cnt && L.ctl[3] == -2;     // uniform: written before the barriers of the energy tree
-        sparse_rows(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1, gathered);
+        sparse_rows<R, PACKED>(P, S, G, A, L, bits, p - (W - 1), 2 * W - 1, true, sidx, eidx - sidx + 1, gathered);
     }
 };
 
