@@ -5,6 +5,7 @@ no MI355X is visible, every entry point raises.  Build with `python __graft_entr
 `make -C hierarchical-sparse-coding_amd/csrc`.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -489,11 +490,14 @@ class Engine(object):
         return self._lib.hscmp_last_variant(self._h).decode()
 
 
-_engines = {}
+_engines = threading.local()
 
 
 def default_engine(device=0):
-    """Process-wide engine per device (the dictionary is re-uploaded when it changes)."""
-    if device not in _engines:
-        _engines[device] = Engine(device)
-    return _engines[device]
+    """One engine per (thread, device): a context is single-threaded (include/hscmp.h), so every thread of the host
+    program gets its own -- the coders of hsc_amd.modeling can then run side by side in a thread pool (the ctypes calls
+    release the interpreter lock; the contexts use separate HIP streams).  The dictionary is re-uploaded when it changes."""
+    table = _engines.__dict__.setdefault('by_device', {})
+    if device not in table:
+        table[device] = Engine(device)
+    return table[device]

@@ -140,6 +140,9 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         """Release the per-level GPU engines (and their workspaces) of computeCoefficientsBatch."""
         for e in self.__dict__.pop('_engines', []):
             e.close()
+        pool = self.__dict__.pop('_host_loop_pool', None)
+        if pool is not None:
+            pool.shutdown(wait=True)          # (its threads' engines go with them)
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
                                  returnDistributed=True, chained=True, memoryBudget=None, epilogue='device', returnEvents=False,
@@ -163,10 +166,25 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         assert residuals in ('samples', 'energy')
         assert _is_multilevel_dict(multilevelDict)
         if self.method != 'cmp':
-            # LoCOMP is a host-driven loop around the GPU hooks: signal by signal
-            out = [self.computeCoefficients(sequences[b], multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
-                                            singletonWeight=singletonWeight, returnDistributed=returnDistributed)
-                   for b in range(sequences.shape[0])]
+            # LoCOMP is a host-driven loop around the GPU hooks: signal by signal, several signals side by side -- every
+            # worker thread drives its own engine (context + stream, _native.default_engine), the GPU calls release the
+            # interpreter lock and overlap on the device
+            def one(b):
+                return self.computeCoefficients(sequences[b], multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
+                                                singletonWeight=singletonWeight, returnDistributed=returnDistributed)
+            nb = sequences.shape[0]
+            workers = max(1, min(int(os.environ.get('HSC_LOCOMP_WORKERS', '8')), nb))
+            if workers > 1:
+                # (the pool is kept: its threads own the engines, whose device buffers are then reused by the next batch)
+                pool = self.__dict__.get('_host_loop_pool')
+                if pool is None or pool._max_workers < workers:
+                    from concurrent.futures import ThreadPoolExecutor
+                    if pool is not None:
+                        pool.shutdown(wait=True)
+                    pool = self.__dict__['_host_loop_pool'] = ThreadPoolExecutor(max_workers=workers)
+                out = list(pool.map(one, range(nb)))
+            else:
+                out = [one(b) for b in range(nb)]
             return [o[0] for o in out], np.stack([o[1] for o in out], axis=0), []
         from . import _native
         from .modeling import _compute_dtype, _slots_to_csc

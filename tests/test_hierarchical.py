@@ -245,11 +245,15 @@ def test_hierarchical_batch_with_locomp_runs_signal_by_signal():
     from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
     z = _golden()
     mld = _mld().withSingletonBases()
-    xs = np.stack([z['x'], (z['x'][::-1]).copy()])
+    rs = np.random.RandomState(2)
+    xs = np.stack([z['x'], (z['x'][::-1]).copy()] + [np.roll(z['x'], int(s)) * np.float32(a) for s, a in zip(rs.randint(1, 200, 10), rs.uniform(0.5, 2.0, 10))])
     hcmp = HierarchicalConvolutionalMatchingPursuit(method='locomp')
     kw = dict(toleranceSnr=[10.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.5)
+    # (twelve signals over the worker threads of the batch path, each with its own engine; twice: the pool is reused)
     coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
-    for b in range(2):
+    coefs2, residuals2, _ = hcmp.computeCoefficientsBatch(xs, mld, **kw)
+    assert np.array_equal(residuals, residuals2)
+    for b in range(xs.shape[0]):
         c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
         for l in range(3):
             assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(c1[l])).nnz == 0
