@@ -183,22 +183,30 @@ class DeviceTable(object):
     def defer_update(self, residual, lo, hi, centres):
         """Record an update (residual samples [lo, hi) changed, rows around `centres` to be re-correlated).  Nothing
         reads the table before the next selection, and a row's value only depends on the residual samples of its
-        window, all of which are final by then -- so the updates of a selection round go to the device as ONE call
-        (the union of the sample ranges, all centres) instead of one per atom."""
+        window, all of which are final by then -- so the updates of a selection round go to the device together: the
+        changed sample ranges (merged where they touch; NOT their hull -- the atoms of a round are spread over the whole
+        signal, and a level >= 1 residual row is F values wide), then all centres in one call."""
         if self._pending is None:
-            self._pending = [lo, hi, residual, list(centres)]
+            self._pending = [[(lo, hi)], residual, list(centres)]
         else:
-            self._pending[0] = min(self._pending[0], lo)
-            self._pending[1] = max(self._pending[1], hi)
-            self._pending[2] = residual
-            self._pending[3].extend(centres)
+            self._pending[0].append((lo, hi))
+            self._pending[1] = residual
+            self._pending[2].extend(centres)
 
     def flush(self):
         self._check_current()
         if self._pending is not None:
-            lo, hi, residual, centres = self._pending
+            ranges, residual, centres = self._pending
             self._pending = None
-            self.engine.table_update(residual[lo:hi], lo, centres)
+            merged = []
+            for lo, hi in sorted(ranges):
+                if merged and lo <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], hi)
+                else:
+                    merged.append([lo, hi])
+            for lo, hi in merged:
+                self.engine.table_update(residual[lo:hi], lo, [])
+            self.engine.table_update(residual[0:0], 0, centres)
 
     def read(self):
         self.flush()
@@ -253,9 +261,7 @@ class Engine(object):
             raise ValueError('weights must have one entry per atom')
         K, W, F = D3.shape
         # the same dictionary again (the row-level hooks of LoCOMP-style callers pass it with every call): nothing to upload
-        import zlib
-        key = (D3.shape, D3.dtype.str, zlib.crc32(D3.view(np.uint8).reshape(-1)), None if w is None else zlib.crc32(w.view(np.uint8)),
-               tuple(sorted(kv for kv in os.environ.items() if kv[0].startswith('HSCMP_'))))    # (diagnostic switches read at upload)
+        key = _dictionary_key(D3, w)
         if key == getattr(self, '_dict_key', None):
             return
         self._dict_key = None
@@ -339,7 +345,10 @@ class Engine(object):
     def table_update(self, residual_rows, start, centres):
         """residual[start:start+len(rows)] := rows on the device, then rows p-(W-1)..p+(W-1) of the table re-correlated
         in place for every centre p (modeling.py:1018-1051)."""
-        rows = np.ascontiguousarray(np.asarray(residual_rows).reshape((len(residual_rows), -1)), dtype=self.dtype)
+        if len(residual_rows) == 0:
+            rows = np.zeros((0, self.F), dtype=self.dtype)
+        else:
+            rows = np.ascontiguousarray(np.asarray(residual_rows).reshape((len(residual_rows), -1)), dtype=self.dtype)
         cs = np.ascontiguousarray(centres, dtype=np.int32)
         self._check(self._lib.hscmp_table_update(self._h, _ptr(rows), int(start), rows.shape[0], _ptr(cs), cs.shape[0]), 'hscmp_table_update')
 
@@ -490,7 +499,16 @@ class Engine(object):
         return self._lib.hscmp_last_variant(self._h).decode()
 
 
+def _dictionary_key(D3, w):
+    """Identity of an uploaded dictionary: shape, dtype, checksums of the CONTENTS (a learner updates its dictionary in
+    place), and the diagnostic switches read at upload."""
+    import zlib
+    return (D3.shape, D3.dtype.str, zlib.crc32(D3.view(np.uint8).reshape(-1)), None if w is None else zlib.crc32(w.view(np.uint8)),
+            tuple(sorted(kv for kv in os.environ.items() if kv[0].startswith('HSCMP_'))))
+
+
 _engines = threading.local()
+kEnginesPerThread = 4
 
 
 def default_engine(device=0):
@@ -501,3 +519,25 @@ def default_engine(device=0):
     if device not in table:
         table[device] = Engine(device)
     return table[device]
+
+
+def engine_for(device, D, weights=None):
+    """An engine of this thread that already HOLDS the dictionary (uploaded, lists built), else the least recently used of
+    up to kEnginesPerThread engines per device, with the dictionary set.  A hierarchical encode alternates between its
+    level dictionaries signal after signal: with one engine every level would upload its dictionary again each time
+    (13 MB and ~0.1 s of list building for config-4 level 1)."""
+    D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)))
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=D3.dtype)
+    key = _dictionary_key(D3, w)
+    pool = _engines.__dict__.setdefault('pool', {}).setdefault(device, [])
+    for i, eng in enumerate(pool):
+        if getattr(eng, '_dict_key', None) == key:
+            pool.append(pool.pop(i))                      # most recently used last
+            return eng
+    if len(pool) < kEnginesPerThread:
+        eng = Engine(device)
+    else:
+        eng = pool.pop(0)
+    pool.append(eng)
+    eng.set_dictionary(D3, w)
+    return eng

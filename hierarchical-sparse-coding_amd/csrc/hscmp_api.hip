@@ -1273,6 +1273,18 @@ extern "C" int hscmp_update_inner_products(hscmp_ctx* ctx, void* ip, const void*
 // Here both live in the context's arena: open = :1293 (innerProducts = convolve1d(residual, D, 'same')), select =
 // _selectBestAtoms (:899-982) on the resident table, update = the caller's new residual samples + _updateInnerProducts
 // (:1018-1051) for every atom of the re-fitted group, in place.  Per iteration the host moves O(W) samples, not T*K.
+// Multi-feature tables (hierarchical levels >= 1) are built row by row from the non-zero cells of each row's window
+// (table_rows_sparse_kernel); single-feature inputs are dense and keep the dense kernels.  HSCMP_FORCE_DENSE: dense always.
+static bool table_rows_are_sparse(const hscmp_ctx* ctx) { return ctx->F > 1 && ctx->W <= 32767 && ctx->F <= 65535 && !getenv("HSCMP_FORCE_DENSE"); }
+constexpr int kTableRowCap = 1024;             // listed non-zeros per row window (12 KB of LDS in float64); more: dense chain
+template <typename R> static void launch_table_rows_sparse(hscmp_ctx* ctx, const R* d_r, int T, int row0, int nrows, int p, R* d_table)
+{
+    DevParams P{};
+    P.B = 1; P.T = T; P.K = ctx->K; P.W = ctx->W; P.F = ctx->F; P.off = (ctx->W - 1) / 2;
+    hipLaunchKernelGGL((table_rows_sparse_kernel<R>), dim3(nrows), dim3(kThreads), (size_t)kTableRowCap * (sizeof(R) + 4), ctx->stream,
+                       P, d_r, (const R*)ctx->d_D, row0, p, d_table, kTableRowCap);
+}
+
 template <typename R> static int run_table_open(hscmp_ctx* ctx, const void* x, int T)
 {
     const int K = ctx->K, F = ctx->F;
@@ -1280,7 +1292,8 @@ template <typename R> static int run_table_open(hscmp_ctx* ctx, const void* x, i
     if ((rc = epi_buffer(ctx, kArenaTabRes, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
     if ((rc = epi_buffer(ctx, kArenaTable, (size_t)T * K * sizeof(R))) != HSCMP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaTabRes], x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
-    launch_convolve<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 1, T, (R*)ctx->d_epi[kArenaTable]);
+    if (table_rows_are_sparse(ctx)) launch_table_rows_sparse<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 0, T, -1, (R*)ctx->d_epi[kArenaTable]);
+    else launch_convolve<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 1, T, (R*)ctx->d_epi[kArenaTable]);
     HIP_TRY(ctx, hipGetLastError());
     ctx->tab_T = T;
     return HSCMP_OK;
@@ -1329,8 +1342,12 @@ extern "C" int hscmp_table_update(hscmp_ctx* ctx, const void* residual_samples, 
     const size_t es = esize(ctx->dtype), row = (size_t)ctx->F * es;
     if (count > 0)
         HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->d_epi[kArenaTabRes] + (size_t)start * row, residual_samples, (size_t)count * row, hipMemcpyHostToDevice, ctx->stream));
+    const bool sparse_rows_form = table_rows_are_sparse(ctx);
     for (int i = 0; i < ncentres; ++i) {
-        if (ctx->dtype == HSCMP_F32) launch_update_rows<float>(ctx, (const float*)ctx->d_epi[kArenaTabRes], T, centres[i], nullptr, (float*)ctx->d_epi[kArenaTable]);
+        if (sparse_rows_form) {
+            if (ctx->dtype == HSCMP_F32) launch_table_rows_sparse<float>(ctx, (const float*)ctx->d_epi[kArenaTabRes], T, 0, 2 * ctx->W - 1, centres[i], (float*)ctx->d_epi[kArenaTable]);
+            else launch_table_rows_sparse<double>(ctx, (const double*)ctx->d_epi[kArenaTabRes], T, 0, 2 * ctx->W - 1, centres[i], (double*)ctx->d_epi[kArenaTable]);
+        } else if (ctx->dtype == HSCMP_F32) launch_update_rows<float>(ctx, (const float*)ctx->d_epi[kArenaTabRes], T, centres[i], nullptr, (float*)ctx->d_epi[kArenaTable]);
         else launch_update_rows<double>(ctx, (const double*)ctx->d_epi[kArenaTabRes], T, centres[i], nullptr, (double*)ctx->d_epi[kArenaTable]);
     }
     HIP_TRY(ctx, hipGetLastError());

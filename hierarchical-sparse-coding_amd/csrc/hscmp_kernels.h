@@ -191,6 +191,85 @@ __global__ __launch_bounds__(kThreads) void corr_init_generic_kernel(DevParams P
     }
 }
 
+// Rows of the inner-product table of a MULTI-FEATURE input (hierarchical levels >= 1: x [T][F] holds the previous level's
+// coefficients and is almost all zeros), for LoCOMP's device-resident table.  One workgroup per output row t:
+//   1. the W x F cells of the row's window are visited in the pinned chain order (f outer, w inner) and the non-zero ones
+//      are compacted, in that order, into an LDS list -- a zero factor contributes fma(0, d, acc) = acc exactly;
+//   2. thread k runs its chain over the list only: table[t][k] = sum x * D[k][w][f].
+// The dense form (corr_init_generic_kernel / update_rows_kernel) forms W*F products per output -- 4352 at config-4 level
+// 1 -- of which ~27 are non-zero.  Rows whose window holds more non-zeros than the list fall back to the dense chain.
+//   p < 0:  rows row0 .. row0+nrows-1 with ZERO padding ('same' initial correlation, modeling.py:159-164), lead = off
+//   p >= 0: rows p-(W-1) .. p+(W-1), REFLECT padding w.r.t. the slice of the update (modeling.py:1018-1051); rows
+//           outside [0, T) are skipped (overlapReplace clipping)
+//   grid = number of rows, block = kThreads, dynamic LDS = cap * (sizeof(R) + 4)
+template <typename R>
+__global__ __launch_bounds__(kThreads) void table_rows_sparse_kernel(DevParams P, const R* __restrict__ r, const R* __restrict__ D, int row0, int p,
+                                                                     R* __restrict__ table, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lx = reinterpret_cast<R*>(smem);
+    int* lwf = reinterpret_cast<int*>(lx + cap);
+    __shared__ int wcount[kWaves];
+    __shared__ int total;
+    const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool reflect = p >= 0;
+    const int t = reflect ? p - (W - 1) + (int)blockIdx.x : row0 + (int)blockIdx.x;
+    if (t < 0 || t >= T) return;                                   // (uniform)
+    int sidx = 0, nslice = 1;
+    if (reflect) {
+        const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);
+        sidx = tstart < 0 ? 0 : tstart;
+        nslice = (tend > T - 1 ? T - 1 : tend) - sidx + 1;
+    }
+    // 1. ordered compaction, 256 cells per pass
+    const int ncell = W * F;
+    int base = 0;
+    bool overflow = false;
+    for (int c0 = 0; c0 < ncell; c0 += kThreads) {
+        const int i = c0 + tid;
+        R xv = (R)0;
+        int wf = 0;
+        if (i < ncell) {
+            const int f = i / W, w = i - f * W;
+            int g = t - P.off + w;
+            if (reflect) { g = reflect_index(g, sidx, nslice); xv = r[(int64_t)g * F + f]; }
+            else xv = (g >= 0 && g < T) ? r[(int64_t)g * F + f] : (R)0;
+            wf = (w << 16) | f;
+        }
+        const unsigned long long mine = __ballot(xv != (R)0);
+        if (lane == 0) wcount[wv] = __popcll(mine);
+        __syncthreads();
+        int before = base;
+        for (int q = 0; q < wv; ++q) before += wcount[q];
+        const int pos = before + __popcll(mine & ((1ull << lane) - 1ull));
+        if (xv != (R)0) { if (pos < cap) { lx[pos] = xv; lwf[pos] = wf; } }
+        int all = 0;
+        for (int q = 0; q < kWaves; ++q) all += wcount[q];
+        base += all;
+        __syncthreads();
+    }
+    overflow = base > cap;                                          // (uniform)
+    const int n = base;
+    // 2. one chain per atom
+    for (int k = tid; k < K; k += kThreads) {
+        const R* dk = D + (int64_t)k * W * F;
+        R acc = (R)0;
+        if (!overflow) {
+            for (int q = 0; q < n; ++q) { const int wf = lwf[q]; acc = rfma(lx[q], dk[(wf >> 16) * F + (wf & 0xffff)], acc); }
+        } else {
+            for (int f = 0; f < F; ++f)
+                for (int w = 0; w < W; ++w) {
+                    int g = t - P.off + w;
+                    R xv;
+                    if (reflect) { g = reflect_index(g, sidx, nslice); xv = r[(int64_t)g * F + f]; }
+                    else xv = (g >= 0 && g < T) ? r[(int64_t)g * F + f] : (R)0;
+                    acc = rfma(xv, dk[w * F + f], acc);
+                }
+        }
+        table[(int64_t)t * K + k] = acc;
+    }
+}
+
 // Window assignment of the convolutional k-means learner (modeling.py:454-460): for each of N windows
 // [L][F] the 'valid' correlation with every atom (Tout = L-W+1 positions) and the flat arg-max of |c|
 // over (position, atom) in C order (ties: lowest position, then lowest atom).

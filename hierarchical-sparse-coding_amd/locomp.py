@@ -36,8 +36,7 @@ class LoCOMP(ConvolutionalMatchingPursuit):
         """:1293 innerProducts = convolve1d(residual, D, padding='same') -- computed and KEPT on the device
         (hscmp_table_open): _selectBestAtoms reads it there, _updateInnerProducts edits it there.  Returns the handle
         (_native.DeviceTable) the two hooks understand."""
-        eng = _native.default_engine(self.device)
-        eng.set_dictionary(np.asarray(D, dtype=dt))
+        eng = _native.engine_for(self.device, np.asarray(D, dtype=dt))
         return eng.table_open(np.asarray(residual, dtype=dt))
 
     def _findCommonSupportAtoms(self, atom, coefficients, D):

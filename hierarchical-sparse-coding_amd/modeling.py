@@ -276,8 +276,7 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         assert F == x.shape[2]
         if weights is not None:
             assert len(weights) == K
-        eng = _native.default_engine(self.device)
-        eng.set_dictionary(D3, None if weights is None else np.asarray(weights, dtype=dt))
+        eng = _native.engine_for(self.device, D3, None if weights is None else np.asarray(weights, dtype=dt))
 
         if maxEvents is None:
             maxEvents = 2 * int(nbNonzeroCoefs) + 64 if nbNonzeroCoefs is not None else 4096

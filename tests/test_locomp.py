@@ -98,6 +98,39 @@ def test_hierarchical_default_method_is_locomp():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('F,density', [(7, 0.05), (40, 0.01), (3, 1.0), (300, 0.9)])
+def test_multi_feature_table_rows_from_the_non_zero_cells(F, density):
+    """Multi-feature tables (hierarchical levels >= 1) are built row by row from the non-zero cells of each row's window
+    (table_rows_sparse_kernel): open and in-place updates against the oracle's dense operations, bit for bit -- sparse
+    inputs, a dense one, and one whose windows overflow the row list (F=300, 90 % non-zero: the dense chain per row)."""
+    from oracle import hsc_oracle as orc
+    from hsc_amd import _native
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit, Atom
+    rs = np.random.RandomState(F)
+    T, K, W = 300, 12, 9
+    D = rs.standard_normal((K, W, F)) * (rs.rand(K, W, F) < 0.3)
+    D /= np.sqrt(np.sum(D ** 2, axis=(1, 2), keepdims=True))
+    x = rs.standard_normal((T, F)) * (rs.rand(T, F) < density)
+    eng = _native.default_engine(0)
+    eng.set_dictionary(D)
+    tab = eng.table_open(x)
+    ip = np.ascontiguousarray(orc.convolve1d(x, D, padding='same'), dtype=np.float64)
+    assert np.array_equal(tab.read(), ip)
+    cmp = ConvolutionalMatchingPursuit()
+    residual = x.copy()
+    for rnd in range(3):
+        atoms = [Atom(0, 1, 0.25, W), Atom(T - 1, 2, -0.5, W), Atom(W, 3, 0.125, W), Atom(int(rs.randint(W, T - W)), int(rs.randint(0, K)), 0.7, W),
+                 Atom(T - 1 - W, 0, 0.3, W)]
+        residual, _ = cmp._updateResidual(residual, 0.0, atoms, D)
+        cmp._updateInnerProducts(tab, residual, atoms, D)
+        for a in atoms:
+            orc.update_inner_products(ip, residual, D, a.position)
+        tb, rb = tab.read(), eng.table_read(table=False, residual=True)[1]
+        assert np.array_equal(tb, ip), rnd
+        assert np.array_equal(rb, residual), rnd
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 def test_device_resident_table_equals_host_table_ops(dtype):
     """hscmp_table_open / _select / _update (the table and the residual stay on the device) against the oracle's
