@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): per-call times of the device-resident LoCOMP table entry points (hscmp_table_open / _select) at the\nconfig-2, config-4 level-1 and long-signal shapes (sparse multi-feature input at level 1)."""
 import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from hsc_amd import _native
 rs = np.random.RandomState(0)
