@@ -17,7 +17,7 @@ x_dev = torch.from_numpy(xs).cuda()
 h = HierarchicalConvolutionalMatchingPursuit(method='cmp')
 for _ in range(2):
     t0 = time.perf_counter()
-    coefs, res, tim = h.computeCoefficientsBatch(xs, mlds, deviceInput=x_dev.data_ptr(), **kw)
+    coefs, res, tim = h.computeCoefficientsBatch(xs, mlds, deviceInput=x_dev.data_ptr(), residuals='energy', **kw)
     print('wall %.1f ms, kernels %.1f ms' % (1e3 * (time.perf_counter() - t0), sum(sum(t['kernel_ms'][:3]) for t in tim)), flush=True)
-cProfile.run("h.computeCoefficientsBatch(xs, mlds, deviceInput=x_dev.data_ptr(), **kw)", '/tmp/hsc.prof')
+cProfile.run("h.computeCoefficientsBatch(xs, mlds, deviceInput=x_dev.data_ptr(), residuals='energy', **kw)", '/tmp/hsc.prof')
 pstats.Stats('/tmp/hsc.prof').sort_stats('cumulative').print_stats(22)
