@@ -9,6 +9,7 @@
 #include "hscmp_kernels.h"
 #include "hscmp_mfma.h"
 #include "hscmp_sparse.h"
+#include "hscmp_rp.h"
 #include "hscmp_epilogue.h"
 
 #include <cmath>
@@ -72,6 +73,7 @@ struct hscmp_ctx {
     bool timed = false;
     bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
     bool mfma_state = false;        // the batch's table-free state is the score-only form of the MFMA kernels
+    bool rp_last = false;           // the last loop launch was the round-parallel form (hscmp_rp.h)
     const void* last_x_dev = nullptr;   // device address of the signals of the last encode (hscmp_hierarchy_epilogue reads them)
     // workspace arena of the entry points outside the batch encode (grow-only, lives as long as the context): slots
     // 0-7 the hierarchical epilogue, 8-15 the row-level entry points and the device-resident table
@@ -440,6 +442,30 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
     return ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
+// Round-parallel loop (hscmp_rp.h: a 1024-thread workgroup per signal, the atoms of a blocked round side by side): for
+// batches that leave CUs idle under one 256-thread workgroup per signal.  HSCMP_RP=0/1 forces the choice (tests run
+// both; the results are bit-identical).
+static bool use_rp(const DevParams& P)
+{
+    if (!P.blocked) return false;
+    if (const char* e = getenv("HSCMP_RP")) return atoi(e) != 0;
+    return P.B <= mfma_device_cus();
+}
+
+// the MFMA loop of a float32 batch: round-parallel when the batch is small and the round is blocked, else iterate_kernel
+template <typename R> static int launch_mfma_loop(hscmp_ctx* ctx, const DevParams& P, const State<R>& S)
+{
+    ctx->rp_last = false;
+    if constexpr (sizeof(R) == 4) {
+        if (use_rp(P) && rp_mfma_launch(ctx->stream, P, S, (const float*)ctx->d_Dfrag, true) == 0) {
+            if (rp_mfma_launch(ctx->stream, P, S, (const float*)ctx->d_Dfrag) != 0) return -1;
+            ctx->rp_last = true;
+            return 0;
+        }
+    }
+    return mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag);
+}
+
 // Loop policy for multi-feature inputs (hierarchical levels >= 1): SparseRecorr gathers the non-zeros
 // of the window into LDS and reads the transposed dictionary coalesced.
 static bool use_sparse_loop(const hscmp_ctx* ctx)
@@ -580,7 +606,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     bool mfi = false;
     if (mf) {
-        if (mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag) != 0)
+        if (launch_mfma_loop<R>(ctx, P, S) != 0)
             return fail(ctx, HSCMP_ERR_HIP, "the MFMA loop could not be launched on the state of the MFMA initial correlation");
         mfi = true;
     }
@@ -592,7 +618,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
     ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
-                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + (mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
+                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + (mfi && ctx->rp_last ? std::string("_rp") : mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
     return HSCMP_OK;
 }
 
@@ -697,10 +723,10 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         int rc;
         if (ctx->dtype == HSCMP_F32) {
             State<float> S = make_state<float>(ctx);
-            rc = mfma_launch_iterate<float>(ctx->stream, P, S, (const float*)ctx->d_Dfrag);
+            rc = launch_mfma_loop<float>(ctx, P, S);
         } else {
             State<double> S = make_state<double>(ctx);
-            rc = mfma_launch_iterate<double>(ctx->stream, P, S, (const double*)ctx->d_Dfrag);
+            rc = launch_mfma_loop<double>(ctx, P, S);
         }
         if (rc != 0) return fail(ctx, HSCMP_ERR_HIP, "hscmp_continue: the MFMA loop could not be launched");
         mfi = true;

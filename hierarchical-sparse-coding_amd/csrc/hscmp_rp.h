@@ -1,0 +1,618 @@
+// hscmp_rp.h -- round-parallel form of the greedy loop, for BLOCKED selection (modeling.py:908-963).
+//
+// iterate_kernel (hscmp_kernels.h) gives a signal ONE team of 256 threads that applies the atoms of a selection
+// round one after the other (modeling.py:1101-1120): at small batches -- BASELINE config 5 is 128 signals per GPU,
+// ~17 k atoms per signal and level -- the run time is the latency of one signal's chain of atoms and most of the chip
+// idles.  A blocked round, however, hands out up to nb+1 atoms at once, and once the interference filter (:951-957)
+// has applied they are pairwise >= W apart: their supports are disjoint.  Then
+//   * the local energies before / after an atom's subtraction (:1002-1005) do not depend on the other atoms of the
+//     round, so the whole bookkeeping chain of the round -- duplicates / nnz (:1106-1111), residual energy (:1014), the
+//     fast stop rules after every atom (:1125-1142), which may cut the round short -- is a PREFIX over per-atom values
+//     that are all known before anything is written;
+//   * a re-correlated row (:1018-1051) reads residual samples that only atoms within W-1 of it change, and each of
+//     those atoms re-correlates the row itself: "all subtractions, then all re-correlations from the final residual"
+//     leaves every row exactly as the sequential loop does (rows that two atoms share are written twice with the same
+//     value).
+// So here a signal owns a 1024-thread workgroup (16 waves, a CU to itself) and a round runs as phases over ALL its atoms:
+//   P1  one wave per block: arg-max of the block (:935-937), its (k, c), local energies, coefficient-slot lookup
+//   P2  null / interference filters, |c| order, weak-atom filter (:946-962, :1090-1099) on index lists in LDS
+//   P3  prefix by one thread: bookkeeping and stop rules in selection order -> how many atoms of the round apply
+//   P4  one wave per atom: residual subtraction                                  | workgroup barrier
+//   P5  one wave per (atom, row tile): re-correlation from the final residual    | workgroup barrier
+//   P6  maxima of the touched segments, slow stop rules (:1145-1163)
+// What is order dependent stays sequential, and exact by construction: an atom whose window crosses a signal end
+// (reflect padding, the stale-sample quirk of DESIGN.md section 2) forms a group of its own inside the round, and a
+// round whose interference filter was skipped (no gap qualifies: its atoms may overlap) runs atom by atom with the
+// energies taken when each atom's turn comes.  Same results as iterate_kernel, bit for bit
+// (tests/test_gpu_round_parallel.py runs both on every case).
+#pragma once
+
+#include "hscmp_mfma.h"
+
+namespace hscmp {
+
+constexpr int kRpWaves = 16;
+constexpr int kRpThreads = 64 * kRpWaves;
+
+enum { RPF_INTERIOR = 1 };      // candidate flags: the atom's 3W-2 window lies inside the signal and no edge quirk applies
+
+template <typename R, int MAXSEG, int MAXSEL> struct RpShared {
+    R seg_score[MAXSEG];
+    int seg_t[MAXSEG];
+    unsigned touched[(MAXSEG + 31) / 32];
+    // candidates of the round, one per block (:935-937)
+    int c_t[MAXSEL]; int c_k[MAXSEL]; R c_c[MAXSEL];
+    R c_eb[MAXSEL]; R c_ea[MAXSEL];           // energy of the atom's clipped window before / after its subtraction
+    int c_found[MAXSEL]; double c_acc[MAXSEL];  // coefficient slot of (t, k) as of the round start (-1: none) and its accumulator
+    int c_flag[MAXSEL];
+    int idx[2][MAXSEL];                         // index lists of the filters (ping-pong)
+    int ord[MAXSEL];                            // the round's atoms in application order
+    int p_si[MAXSEL]; int p_ev[MAXSEL];       // plan of the prefix: slot (bit 31: new) and event index, per ordered position
+    int wtot[kRpWaves];
+    // control block (written by thread 0, read by all behind a barrier)
+    int converged, stop, napply;
+    int nnz, ndup, rounds, iters, nev, nslots, offset;
+    R e_sig, e_res;
+};
+
+// stable compaction over the workgroup: thread i keeps `value` iff `keep`; dst[0..count) in thread order; returns count
+template <typename SH> __device__ __forceinline__ int rp_compact(SH& sh, bool keep, int value, int* dst)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) sh.wtot[wv] = __popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < kRpWaves; ++q) { const int c = sh.wtot[q]; if (q < wv) before += c; total += c; }
+    if (keep) dst[before + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+    __syncthreads();
+    return total;
+}
+
+// segment maximum of the per-position best (score, first position) by one wave
+template <bool SO, typename R, typename SH>
+__device__ __forceinline__ void rp_scan_segment(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
+{
+    const int t0 = (sg << P.seg_shift);
+    const int t1 = min(P.T, t0 + P.seg);
+    Cand<R> win = wave_range_argmax<SO>(G, w, t0, t1, lane);
+    if (lane == 0) {
+        if (win.i == INT_MAX) { win.i = t0; win.s = (R)0; }
+        sh.seg_score[sg] = win.s;
+        sh.seg_t[sg] = win.i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the round-parallel loop          grid = B, block = kRpThreads
+//   Pol supplies the per-wave pieces: candidate (resolve + energies), energies, subtract, recorrelate.
+// ------------------------------------------------------------------------------------------------
+template <typename R, typename Pol>
+__global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, State<R> S, typename Pol::Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using SH = typename Pol::Shared;
+    constexpr int MAXSEL = Pol::kMaxSel;
+    SH& sh = *reinterpret_cast<SH*>(smem);
+    char* plds = smem + ((sizeof(SH) + 15) / 16) * 16;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int* stats = S.stats + (int64_t)b * ST_COUNT;
+    if (stats[ST_STOP] != STOP_RUNNING) return;          // converged in an earlier launch (uniform)
+
+    const int T = P.T, W = P.W, F = P.F;
+    Sig<R> G;
+    G.r = S.residual + (int64_t)b * T * F;
+    G.bc = S.best_c + (int64_t)b * T;
+    G.bk = S.best_k + (int64_t)b * T;
+    G.ev_t = S.ev_t + (int64_t)b * P.cap; G.ev_k = S.ev_k + (int64_t)b * P.cap; G.ev_c = S.ev_c + (int64_t)b * P.cap;
+    G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
+    G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
+    G.sel_t = nullptr; G.sel_k = nullptr; G.sel_c = nullptr;
+
+    Pol::prologue(P, S, G, A, plds, b);                  // (ends with a workgroup barrier)
+    const R* wts = Pol::weights(P, S, A, plds);
+
+    // ---- segment maxima; the (t,k) -> slot table of this launch, from the slot list (always on: the probes of a
+    //      round go out side by side, one per candidate)
+    for (int sg = wv; sg < P.nseg; sg += kRpWaves) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
+    for (unsigned i = tid; i <= P.hmask; i += kRpThreads) hkey_store(G.hkey + i, kSlotEmpty);
+    for (int i = tid; i < (Pol::kMaxSegments + 31) / 32; i += kRpThreads) sh.touched[i] = 0u;
+    if (tid == 0) {
+        sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
+        sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
+        sh.converged = 0; sh.stop = STOP_RUNNING; sh.napply = 0;
+        sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
+    }
+    __syncthreads();
+    {
+        const int ns = stats[ST_SLOTS];
+        for (int i = tid; i < ns; i += kRpThreads) slot_insert(G, P.hmask, G.slot_t[i], G.slot_k[i], i);
+    }
+    __syncthreads();
+
+    const double thres = P.thres;
+    const bool has_thres = P.has_thres != 0;
+    HSCMP_STAMP_BEGIN();
+    for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
+        HSCMP_STAMP(16);                                                      // round end of the previous round
+        // =========================== P1: one arg-max per block (:908-937) ===========================
+        const int off = sh.offset;
+        const int nb = P.nbk + (off ? 1 : 0);
+        const int pad0 = off ? P.bs / 2 : 0;
+        for (int j = wv; j < nb; j += kRpWaves) {
+            const int w0 = j * P.bs - pad0;
+            const int lo = w0 < 0 ? 0 : w0;
+            const int hi = min(T, w0 + P.bs);
+            Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
+            if (lo < hi) win = wave_block_argmax<Pol::kScoreOnly>(P, G, wts, sh, lo, hi, lane);
+            bool valid = (lo < hi) && win.i != INT_MAX;                      // :940-942 range test
+            if (valid && win.s == (R)0 && w0 < 0) valid = false;             // arg-max on a leading padded row
+            int wk = 0, flag = 0, found = -1;
+            R wc = (R)0, eb = (R)0, ea = (R)0;
+            double acc = 0.0;
+            if (valid) {                                                     // wave-uniform
+                Pol::candidate(P, S, G, A, plds, win.i, lane, wv, wk, wc, eb, ea, flag);
+                if (lane == 0) {
+                    unsigned pos;
+                    found = slot_find(G, P.hmask, win.i, wk, pos);
+                    if (found >= 0) acc = G.slot_a[found];
+                }
+            }
+            if (lane == 0) {
+                sh.c_t[j] = valid ? win.i : -1; sh.c_k[j] = wk; sh.c_c[j] = wc; sh.c_eb[j] = eb; sh.c_ea[j] = ea;
+                sh.c_found[j] = found; sh.c_acc[j] = acc; sh.c_flag[j] = flag;
+            }
+        }
+        __syncthreads();
+        HSCMP_STAMP(17);                                                      // block arg-max + candidates
+        // =========================== P2: filters and order (:946-962, :1090-1099) ===========================
+        int n;
+        bool spaced = true;                                                  // the atoms of the round are pairwise >= W apart
+        {
+            int* la = sh.idx[0]; int* lb = sh.idx[1];
+            // :946-948 drop null coefficients (and invalid blocks)
+            n = rp_compact(sh, tid < nb && sh.c_t[tid] >= 0 && (!has_thres || fabs((double)sh.c_c[tid]) > thres), tid, la);
+            // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
+            if (n > 1) {
+                const bool gap = tid >= 1 && tid < n && (sh.c_t[la[tid]] - sh.c_t[la[tid - 1]] >= W);
+                if (__syncthreads_or(gap ? 1 : 0)) {
+                    n = rp_compact(sh, tid < n && (tid == 0 || gap), tid < n ? la[tid] : 0, lb);
+                    int* tmp = la; la = lb; lb = tmp;
+                } else {
+                    spaced = false;
+                }
+            }
+            // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals (rank sort)
+            if (tid < n) {
+                const int me = la[tid];
+                const R a = rabs(sh.c_c[me]);
+                int rank = 0;
+                for (int q = 0; q < n; ++q) {
+                    const R o = rabs(sh.c_c[la[q]]);
+                    rank += (o > a || (o == a && q > tid)) ? 1 : 0;
+                }
+                lb[rank] = me;
+            }
+            __syncthreads();
+            { int* tmp = la; la = lb; lb = tmp; }
+            // :1090-1099 weak-atom filter: the window of the filter is the atom's clipped support, its energy c_eb
+            if (P.has_snr && n > 1) {
+                const R tol_energy = sh.e_sig / (R)P.snr_ratio;
+                const double thr = (double)tol_energy / (double)((int64_t)T * F);
+                bool keep = false;
+                if (tid < n) {
+                    const int me = la[tid];
+                    int s, e, es;
+                    const int len = centered_span(T, W, sh.c_t[me], s, e, es);
+                    const R mean = sh.c_eb[me] / (R)((int64_t)len * F);
+                    keep = (double)mean >= thr;
+                }
+                n = rp_compact(sh, keep, tid < MAXSEL ? la[tid] : 0, lb);
+                int* tmp = la; la = lb; lb = tmp;
+            }
+            if (tid < n) sh.ord[tid] = la[tid];
+        }
+        // atoms that form a group of their own (signal ends); uniform
+        const int nedge = __syncthreads_count((tid < n && !(sh.c_flag[sh.ord[tid]] & RPF_INTERIOR)) ? 1 : 0);
+        HSCMP_STAMP(18);                                                      // filters + sort
+        // A round whose atoms do not all fit the event list is not started: the state then is exactly that of a round
+        // boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
+        if (sh.nev + n > P.cap) {                                            // uniform (LDS, behind a barrier)
+            __syncthreads();
+            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
+            break;
+        }
+        // =========================== P3-P5: apply the atoms (:1101-1142), group by group ===========================
+        int pos = 0;
+        while (pos < n) {
+            int gend;
+            if (!spaced) {
+                // overlapping atoms: one at a time, energies as of its turn
+                gend = pos + 1;
+                if (pos > 0) {
+                    if (wv == 0) {
+                        const int me = sh.ord[pos];
+                        R eb, ea;
+                        Pol::energies(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv, eb, ea);
+                        if (lane == 0) { sh.c_eb[me] = eb; sh.c_ea[me] = ea; }
+                    }
+                    __syncthreads();
+                }
+            } else if (nedge == 0) {
+                gend = n;
+            } else if (!(sh.c_flag[sh.ord[pos]] & RPF_INTERIOR)) {
+                gend = pos + 1;
+            } else {
+                gend = pos + 1;
+                while (gend < n && (sh.c_flag[sh.ord[gend]] & RPF_INTERIOR)) ++gend;
+            }
+            // ---- P3: bookkeeping and fast stop rules of the group in selection order (:1106-1142)
+            if (tid == 0) {
+                int i = pos;
+                for (; i < gend; ++i) {
+                    const int me = sh.ord[i];
+                    const R c = sh.c_c[me];
+                    int si = sh.c_found[me];
+                    if (si >= 0 && fabs(sh.c_acc[me]) > 0.0) sh.ndup += 1;
+                    else if (rabs(c) > (R)0) sh.nnz += 1;
+                    const bool fresh = si < 0;
+                    if (fresh) si = sh.nslots++;
+                    sh.p_si[i] = si | (fresh ? (int)0x80000000 : 0);
+                    sh.p_ev[i] = sh.nev++;
+                    const R loss = sh.c_eb[me] - sh.c_ea[me];            // :1005
+                    sh.e_res = sh.e_res - loss;                          // :1014
+                    sh.iters += 1;
+                    if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
+                    else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
+                    else if (P.has_snr) {
+                        const R q = sh.e_sig / sh.e_res;
+                        if ((double)q >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
+                    }
+                    if (sh.converged) { ++i; break; }
+                }
+                sh.napply = i;
+            }
+            __syncthreads();
+            const int aend = sh.napply;
+            HSCMP_STAMP(19);                                                  // prefix
+            // coefficient slots and events of the applied atoms (:1114), one thread per atom
+            if (tid >= pos && tid < aend) {
+                const int me = sh.ord[tid];
+                const int t = sh.c_t[me], k = sh.c_k[me];
+                const R c = sh.c_c[me];
+                const int si = sh.p_si[tid] & 0x7fffffff, ev = sh.p_ev[tid];
+                if (sh.p_si[tid] < 0) { G.slot_t[si] = t; G.slot_k[si] = k; slot_insert(G, P.hmask, t, k, si); }
+                G.slot_a[si] = sh.c_acc[me] + (double)c;                     // (:992: a new accumulator starts at 0.0)
+                G.ev_t[ev] = t; G.ev_k[ev] = k; G.ev_c[ev] = c;
+            }
+            // ---- P4: residual subtraction (:1117, :996-1016), one wave per atom
+            for (int i = pos + wv; i < aend; i += kRpWaves) {
+                const int me = sh.ord[i];
+                Pol::subtract(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv);
+            }
+            __syncthreads();
+            HSCMP_STAMP(20);                                                  // subtraction
+            // ---- P5: local re-correlation of the touched rows from the final residual (:1120, :1018-1051)
+            {
+                const int upa = Pol::units_per_atom(P);
+                const int nu = (aend - pos) * upa;
+                for (int u = wv; u < nu; u += kRpWaves) {
+                    const int a = u / upa, q = u - a * upa;
+                    const int me = sh.ord[pos + a];
+                    const int p = sh.c_t[me];
+                    Pol::recorrelate(P, S, G, A, plds, p, sh.c_k[me], q, (sh.c_flag[me] & RPF_INTERIOR) != 0, lane, wv);
+                    if (q == 0 && lane == 0) {
+                        const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
+                        for (int sg = lo >> P.seg_shift; sg <= (hi >> P.seg_shift); ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
+                    }
+                }
+            }
+            __syncthreads();
+            HSCMP_STAMP(21);                                                  // re-correlation
+            if (nedge > 0 || !spaced) {
+                if (tid == 0)
+                    for (int i = pos; i < aend; ++i) {
+                        const int me = sh.ord[i];
+                        if (!(sh.c_flag[me] & RPF_INTERIOR)) Pol::after_atom(P, A, plds, sh.c_t[me]);
+                    }
+                __syncthreads();
+            }
+            if (sh.converged) break;
+            pos = gend;
+        }
+        // =========================== P6: segment maxima, slow stop rules (:1145-1163) ===========================
+        if (n > 0 && !sh.converged) {
+            // every wave walks the set bits (lane l holds word l) and takes every 16th touched segment
+            constexpr int kWords = (Pol::kMaxSegments + 31) / 32;
+            static_assert(kWords <= 64, "one mask word per lane");
+            const unsigned word = lane < kWords ? sh.touched[lane] : 0u;
+            unsigned long long words = __ballot(word != 0u);
+            int r = 0;
+            while (words) {                                                  // wave-uniform
+                const int wl = __ffsll((long long)words) - 1;
+                words &= words - 1ull;
+                unsigned bits = __shfl(word, wl);
+                while (bits) {
+                    const int sg = wl * 32 + __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    if (((r++) & (kRpWaves - 1)) != wv) continue;
+                    rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
+                }
+            }
+        }
+        if (tid == 0) {
+            if (n == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }     // :1150-1153
+            sh.rounds += 1;
+            sh.offset = !sh.offset;
+        }
+        __syncthreads();
+        if (tid < (Pol::kMaxSegments + 31) / 32) sh.touched[tid] = 0u;      // (next marked several barriers from here)
+        HSCMP_STAMP(22);                                                      // segment maxima + round end
+#ifdef HSCMP_DBG_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[30] += 1; g_stamps[31] += (unsigned long long)n; }
+#endif
+        if (sh.converged) break;
+    }
+
+    __syncthreads();
+    Pol::epilogue(P, S, A, plds, b);
+    if (tid == 0) {
+        stats[ST_NNZ] = sh.nnz; stats[ST_DUP] = sh.ndup; stats[ST_ROUNDS] = sh.rounds; stats[ST_STOP] = sh.stop;
+        stats[ST_ITERS] = sh.iters; stats[ST_EVENTS] = sh.nev; stats[ST_SLOTS] = sh.nslots; stats[ST_OFFSET] = sh.offset;
+        S.energy[2 * b + 1] = sh.e_res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Policy for single-feature float32 signals on the matrix cores (the score-only state of hscmp_mfma.h):
+// every piece is the work of ONE wave with a strip of LDS of its own.
+// LDS behind the control block: [dictionary image | weights][edge words][per wave: resolve window | tile window]
+// ------------------------------------------------------------------------------------------------
+template <int S4C, bool HAS_W> struct RpMfma {
+    static_assert(S4C > 0, "compile-time chunk count only");
+    using R = float;
+    using Tile = TileF32;
+    static constexpr int kMaxSegments = kMfmaMaxSeg;
+    static constexpr int kMaxSel = 512;
+    static constexpr bool kScoreOnly = true;
+    static constexpr int TP = 32;
+    using Shared = RpShared<float, kMfmaMaxSeg, kMaxSel>;
+    using Args = MfmaArgs;
+    static constexpr int kRw = 8 * S4C;                  // resolve window: W taps, zero padded
+    static constexpr int kWin = TP + 8 * S4C + 32;       // tile window: 32 positions + taps (+ slack of the kk offset)
+
+    struct Layout { float* dimg; float* wts; unsigned long long* edge; float* rw; float* win; };
+    static __host__ __device__ size_t policy_lds_bytes(const Args& A)
+    {
+        return ((size_t)A.G * S4C * 256 + (HAS_W ? 32 * A.G : 0)) * sizeof(float) + kEdgeWords * sizeof(unsigned long long) +
+               (size_t)kRpWaves * (kRw + kWin) * sizeof(float);
+    }
+    static size_t total_lds_bytes(const Args& A) { return ((sizeof(Shared) + 15) / 16) * 16 + policy_lds_bytes(A); }
+    static __device__ __forceinline__ Layout layout(const Args& A, char* lds)
+    {
+        Layout L;
+        L.dimg = reinterpret_cast<float*>(lds);
+        L.wts = L.dimg + A.G * S4C * 256;
+        L.edge = reinterpret_cast<unsigned long long*>(L.wts + (HAS_W ? 32 * A.G : 0));
+        L.rw = reinterpret_cast<float*>(L.edge + kEdgeWords);
+        L.win = L.rw + kRpWaves * kRw;
+        return L;
+    }
+    static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
+    static __device__ __forceinline__ int units_per_atom(const DevParams& P) { return (2 * P.W - 1 + TP - 1) / TP; }
+
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Sig<R>&, const Args& A, char* lds, int b)
+    {
+        const Layout L = layout(A, lds);
+        lds_copy16(L.dimg, A.dimg, A.G * S4C * 256 * (int)sizeof(float), (int)threadIdx.x, kRpThreads);
+        if (HAS_W) for (int i = threadIdx.x; i < 32 * A.G; i += kRpThreads) L.wts[i] = i < P.K ? S.weights[i] : 0.0f;
+        for (int i = threadIdx.x; i < kRpWaves * (kRw + kWin); i += kRpThreads) L.rw[i] = 0.0f;      // padded taps stay zero
+        if (threadIdx.x < kEdgeWords) L.edge[threadIdx.x] = S.edge[kEdgeWords * b + threadIdx.x];
+        __syncthreads();
+    }
+    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>& S, const Args& A, char* lds, int b)
+    {
+        const Layout L = layout(A, lds);
+        if (threadIdx.x < kEdgeWords) S.edge[kEdgeWords * b + threadIdx.x] = L.edge[threadIdx.x];
+    }
+
+    // the edge quirks of DESIGN.md section 2 make an atom order dependent: such atoms are applied alone
+    static __device__ __forceinline__ bool is_interior(const DevParams& P, int p)
+    {
+        const int tstart = p - P.off - (P.W - 1), tend = p + P.W / 2 + (P.W - 1);
+        return tstart >= 0 && tend <= P.T - 1 && !(!(P.W & 1) && p == P.T - 1 - P.W);
+    }
+
+    // local energies (:1002-1005) of the atom (k, c) at t from the window in `rw` (rw[w] = sample t - off + w): the pinned
+    // tree over 256 strided partial sums, of which the window fills the first len <= 128 with one square each
+    static __device__ __forceinline__ void window_energies(const DevParams& P, const Layout& L, const float* rw, int t, int k, float c,
+                                                           int lane, float& eb, float& ea)
+    {
+        int s, e, es;
+        const int len = centered_span(P.T, P.W, t, s, e, es);
+        const float nc = -c;
+        float pb[2] = {0.0f, 0.0f}, pa[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = lane + 64 * u;
+            if (q < len) {
+                const float v = rw[es + q];
+                const float prod = nc * L.dimg[dimg_index(k, es + q, S4C)];      // -c*D[k] rounded, then += (utils.py:120,129)
+                const float vn = v + prod;
+                pb[u] = v * v; pa[u] = vn * vn;
+            }
+        }
+        wave_tree_down2(pb[0], pa[0]);
+        wave_tree_down2(pb[1], pa[1]);
+        const float b01 = pb[0] + pb[1], a01 = pa[0] + pa[1];                    // (P0 + P1) + (P2 + P3), the last two +0
+        eb = b01 + 0.0f; ea = a01 + 0.0f;
+    }
+
+    static __device__ __forceinline__ void load_window(const DevParams& P, const Sig<R>& G, const Layout& L, float* rw, int t, int lane)
+    {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float wres[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (lane + 64 * u < P.W) wres[u] = edge_window_value(G.r, P.T, t - P.off + lane + 64 * u, t, L.edge);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (lane + 64 * u < P.W) rw[lane + 64 * u] = wres[u];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // (k, c) of position t (:935-946) from its group hint, local energies of that atom; all by one wave
+    static __device__ __forceinline__ void candidate(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds,
+                                                     int t, int lane, int wv, int& k_out, R& c_out, R& eb, R& ea, int& flag)
+    {
+        const Layout L = layout(A, lds);
+        float* rw = L.rw + wv * kRw;
+        const int gh = G.bk[t];                                 // the hint travels with the window's samples
+        load_window(P, G, L, rw, t, lane);
+        const int g = __builtin_amdgcn_readfirstlane(gh);
+        const int k = 32 * g + lane;
+        Cand<R> best; best.s = -1.0f; best.i = INT_MAX;
+        float bc = 0.0f;
+        if (lane < 32 && k < P.K) {
+            bc = resolve_chain<S4C>(L.dimg, rw, k, S4C);
+            if (HAS_W) { const float sw = bc * L.wts[k]; best.s = fabsf(sw); } else best.s = fabsf(bc);
+            best.i = k;
+        }
+        best = wave_argmax_first(best);                         // (lane l holds atom 32 g + l: lanes in index order)
+        k_out = __builtin_amdgcn_readfirstlane(best.i);
+        c_out = wave_bcast(bc, best.i & 31);
+        window_energies(P, L, rw, t, k_out, c_out, lane, eb, ea);
+        flag = is_interior(P, t) ? RPF_INTERIOR : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    static __device__ __forceinline__ void energies(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds,
+                                                    int t, int k, R c, int lane, int wv, R& eb, R& ea)
+    {
+        const Layout L = layout(A, lds);
+        float* rw = L.rw + wv * kRw;
+        load_window(P, G, L, rw, t, lane);
+        window_energies(P, L, rw, t, k, c, lane, eb, ea);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    static __device__ __forceinline__ void subtract(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds,
+                                                    int p, int k, R c, int lane, int)
+    {
+        const Layout L = layout(A, lds);
+        const int T = P.T, W = P.W;
+        int s, e, es;
+        const int len = centered_span(T, W, p, s, e, es);
+        const float nc = -c;
+        float v[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (lane + 64 * u < len) v[u] = G.r[s + lane + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = lane + 64 * u;
+            if (q < len) {
+                const int m = s + q;
+                const float prod = nc * L.dimg[dimg_index(k, es + q, S4C)];
+                const float vn = v[u] + prod;
+                // even W: an atom at T-1-W changes the sample that row T-1 reads through the reflection without
+                // re-correlating that row -- keep what row T-1 saw (edge_window_value, hscmp_mfma.h)
+                if (!(W & 1) && p == T - 1 - W && m == T - 1 - W / 2 && (L.edge[1] & 1ull) && L.edge[2] == 0ull) {
+                    L.edge[3] = edge_bits_of(v[u]);
+                    L.edge[2] = (unsigned long long)(m + 1);
+                }
+                G.r[m] = vn;
+            }
+        }
+    }
+
+    // rows 32 q .. 32 q + 31 of the atom's 2W-1 touched rows, from the (final) residual
+    static __device__ __forceinline__ void recorrelate(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds,
+                                                       int p, int, int q, bool interior, int lane, int wv)
+    {
+        const Layout L = layout(A, lds);
+        const int T = P.T, W = P.W;
+        float* win = L.win + wv * kWin;
+        const int nrows = 2 * W - 1, span = 3 * W - 2;
+        const int tstart = p - P.off - (W - 1);                 // :1028-1033
+        const int tend = p + W / 2 + (W - 1);                   // :1038
+        const int sidx = tstart < 0 ? 0 : tstart;               // :1034
+        const int eidx = tend > T - 1 ? T - 1 : tend;           // :1039
+        const int nslice = eidx - sidx + 1;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int kU = (TP + 8 * S4C + 63) / 64;
+        float v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = lane + 64 * u, jj = TP * q + i;
+            v[u] = 0.0f;
+            if (i < TP + 8 * S4C && jj < span)                  // np.pad 'reflect', :1046; behind the span: zeros
+                v[u] = G.r[interior ? tstart + jj : reflect_index(tstart + jj, sidx, nslice)];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int i = lane + 64 * u; if (i < TP + 8 * S4C) win[i] = v[u]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int grp;
+        const float sc = mfma_tile_score_lean<S4C, HAS_W>(L.dimg, win, L.wts, A.G, lane, grp);
+        const int row = TP * q + lane, t = p - (W - 1) + row;
+        if (lane < TP && row < nrows && t >= 0 && t < T) {      // overlapReplace clipping (utils.py:133-161)
+            G.bc[t] = sc;
+            G.bk[t] = grp;                                      // the group hint of the row
+        }
+    }
+
+    // rows lo..hi of an atom near a signal end now carry reflect-padded values (edge_window_value); one thread
+    static __device__ __forceinline__ void after_atom(const DevParams& P, const Args& A, char* lds, int p)
+    {
+        const Layout L = layout(A, lds);
+        const int T = P.T, W = P.W;
+        const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
+        if (lo < P.off) L.edge[0] |= bit_range(lo, min(hi, P.off - 1));
+        const int rt0 = T - (W - 1 - P.off);                    // first position whose window passes T-1
+        if (hi >= rt0) L.edge[1] |= bit_range(T - 1 - hi, T - 1 - max(lo, rt0));
+        if (hi >= T - 1) L.edge[2] = 0ull;                      // row T-1 re-correlated: nothing stale any more
+    }
+};
+
+// host-side dispatch -----------------------------------------------------------------------------
+// can the round-parallel loop run these parameters at all (the policies add their own shape tests)
+inline bool rp_params_ok(const DevParams& P, int maxsel_cap)
+{
+    return P.blocked && !P.has_scale && !P.select_only && P.maxsel <= maxsel_cap;
+}
+
+template <int S4C, bool HAS_W>
+static int rp_mfma_launch_t(hipStream_t stream, const DevParams& P0, const State<float>& S, const MfmaArgs& A, bool dry)
+{
+    using Pol = RpMfma<S4C, HAS_W>;
+    DevParams P = P0;
+    set_segments(P, Pol::kMaxSegments);
+    const size_t lds = Pol::total_lds_bytes(A);
+    if (lds > (size_t)160 * 1024) return -1;
+    auto kern = iterate_rp_kernel<float, Pol>;
+    if (set_dyn_lds((const void*)kern, lds) != hipSuccess) return -1;
+    if (dry) return 0;
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kRpThreads), lds, stream, P, S, A);
+    return 0;
+}
+
+// 0: launched (or, dry, could be); -1: this shape has no round-parallel form
+inline int rp_mfma_launch(hipStream_t stream, const DevParams& P, const State<float>& S, const float* dimg, bool dry = false)
+{
+    if (!rp_params_ok(P, 512) || P.F != 1 || P.T < 3 * P.W - 2) return -1;
+    const MfmaArgs A = mfma_args<float>(P, S, dimg);
+    const bool hw = A.has_w != 0;
+    switch (A.S4) {
+    case 8: return hw ? rp_mfma_launch_t<8, true>(stream, P, S, A, dry) : rp_mfma_launch_t<8, false>(stream, P, S, A, dry);
+    case 4: return hw ? rp_mfma_launch_t<4, true>(stream, P, S, A, dry) : rp_mfma_launch_t<4, false>(stream, P, S, A, dry);
+    case 2: return hw ? rp_mfma_launch_t<2, true>(stream, P, S, A, dry) : rp_mfma_launch_t<2, false>(stream, P, S, A, dry);
+    default: return -1;
+    }
+}
+
+}  // namespace hscmp

@@ -1,0 +1,120 @@
+"""The round-parallel loop (csrc/hscmp_rp.h: a 1024-thread workgroup per signal applies the atoms of a blocked
+selection round side by side) against the one-atom-at-a-time loop (iterate_kernel) and the CPU oracle, bit for bit.
+
+HSCMP_RP=1 / 0 force either loop (read at every launch); by default the dispatcher picks the round-parallel form for
+blocked selection when the batch leaves CUs idle, so the rest of the -m gpu suite (fuzz sweeps, edges, goldens) runs it
+wherever it applies as well."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _encode(xs, D, forced, monkeypatch, **kw):
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    monkeypatch.setenv('HSCMP_RP', forced)
+    cmp = ConvolutionalMatchingPursuit()
+    res = cmp.computeCoefficientsBatch(xs, D, **kw)
+    return res
+
+
+def _same(a, b, B):
+    for i in range(B):
+        for u, v in zip(a.events[i], b.events[i]):
+            assert np.array_equal(u, v), i
+        assert np.array_equal(a.residuals[i], b.residuals[i]), i
+    assert np.array_equal(a.stats, b.stats)
+
+
+CASES = [
+    # (K, W, T, nbBlocks, kwargs)
+    (32, 32, 4096, 10, dict(nbNonzeroCoefs=64)),
+    (32, 32, 4096, 'auto', dict(nbNonzeroCoefs=100)),
+    (128, 32, 8192, 10, dict(toleranceSnr=25.0)),
+    (70, 16, 3000, 7, dict(toleranceSnr=15.0, nbNonzeroCoefs=200)),
+    (256, 64, 8192, 10, dict(toleranceSnr=20.0)),
+    (96, 64, 4100, 'auto', dict(nbNonzeroCoefs=120)),
+    (33, 8, 1000, 3, dict(toleranceSnr=30.0)),
+    (48, 60, 5000, 5, dict(nbNonzeroCoefs=80)),
+]
+
+
+@pytest.mark.parametrize('case', range(len(CASES)))
+@pytest.mark.parametrize('weighted', [False, True])
+def test_round_parallel_vs_sequential_vs_oracle(case, weighted, monkeypatch):
+    import hsc_amd.synth as synth
+    from oracle import hsc_oracle as orc
+    K, W, T, nb, kw = CASES[case]
+    kw = dict(kw, nbBlocks=nb)
+    D = synth.make_dictionary(K, W, seed=30 + case)
+    xs = np.stack([synth.make_signal(D, T, i, kind='planted' if i % 3 else 'noise', nb_atoms=max(8, T // (3 * W)), noise=0.05, seed=31 + case)
+                   for i in range(5)])
+    xs[4, : 2 * W] *= 6.0                                       # energy piled at the left end: atoms whose windows cross it
+    xs[3, -2 * W:] *= 6.0
+    if weighted:
+        kw['weights'] = np.random.RandomState(case).uniform(0.6, 1.0, size=K).astype(np.float32)
+    rp = _encode(xs, D, '1', monkeypatch, **kw)
+    # (built for dictionaries of 2, 4 or 8 chunks of 8 taps; other widths keep the sequential loop)
+    assert rp.variant.endswith('_rp') == ((W + 7) // 8 in (2, 4, 8)), rp.variant
+    seq = _encode(xs, D, '0', monkeypatch, **kw)
+    assert not seq.variant.endswith('_rp'), seq.variant
+    _same(rp, seq, xs.shape[0])
+    for i in (0, 3, 4):
+        coef, r, info = orc.cmp_encode(xs[i], D, **kw)
+        t, k, c = rp.events[i]
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), (case, i)
+        assert np.array_equal(np.squeeze(rp.residuals[i]), r), (case, i)
+        assert rp.stop_reasons()[i] == info['stop']
+
+
+@pytest.mark.parametrize('W', [12, 16, 32])
+def test_round_whose_interference_filter_is_skipped(W, monkeypatch):
+    """Two strong atoms closer than W on either side of a block boundary, nothing else: the candidates of the round have no
+    qualifying gap, modeling.py:951-957 skips the filter, and the overlapping atoms must be applied one after the other
+    with the energies of their turn."""
+    import hsc_amd.synth as synth
+    from oracle import hsc_oracle as orc
+    K, T = 24, 64 * W
+    D = synth.make_dictionary(K, W, seed=50 + W)
+    xs = np.zeros((3, T), dtype=np.float32)
+    for i, (gap, nbk) in enumerate([(3, 2), (W - 1, 4), (W // 2, 8)]):
+        edge = (T // nbk) * (nbk // 2)                         # a block boundary of the un-shifted rounds
+        for p, k, c in ((edge - gap // 2 - 1, 3, 2.5), (edge + gap - gap // 2 - 1, 7, -1.75)):
+            lo = p - (W - 1) // 2
+            xs[i, lo:lo + W] += c * D[k]
+    for i, nbk in enumerate([2, 4, 8]):
+        kw = dict(nbBlocks=nbk, nbNonzeroCoefs=12)
+        rp = _encode(xs[i:i + 1], D, '1', monkeypatch, **kw)
+        assert rp.variant.endswith('_rp')
+        seq = _encode(xs[i:i + 1], D, '0', monkeypatch, **kw)
+        _same(rp, seq, 1)
+        coef, r, info = orc.cmp_encode(xs[i], D, **kw)
+        t, k, c = rp.events[0]
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), (W, i)
+        assert np.array_equal(np.squeeze(rp.residuals[0]), r)
+
+
+def test_round_parallel_resumes_after_event_list_growth(monkeypatch):
+    import hsc_amd.synth as synth
+    D = synth.make_dictionary(64, 32, seed=60)
+    xs = synth.make_batch(D, 8192, 0, 3, kind='planted', nb_atoms=120, noise=0.02, seed=60)
+    kw = dict(nbBlocks=10, toleranceSnr=30.0)
+    full = _encode(xs, D, '1', monkeypatch, **kw)
+    short = _encode(xs, D, '1', monkeypatch, maxEvents=4, **kw)   # grown in place, the loop resumed several times
+    _same(full, short, 3)
+
+
+def test_config5_level0_dims_three_runs(monkeypatch):
+    """BASELINE config 5, level 0 (128 atoms x 32 taps, 65536 samples, toleranceSnr 30, nbBlocks=10; ~17 k atoms per
+    signal): both loops on every signal, the round-parallel one three times, bit for bit."""
+    import hsc_amd.synth as synth
+    D = synth.make_dictionary(128, 32, seed=5)
+    B, T = 24, 65536
+    xs = np.stack([synth.make_signal(D, T, i, kind='planted', nb_atoms=T // 6, noise=0.02, seed=5) for i in range(B)])
+    kw = dict(nbBlocks=10, toleranceSnr=30.0)
+    seq = _encode(xs, D, '0', monkeypatch, **kw)
+    assert int(seq.stats[:, 4].min()) > 3000                    # thousands of atoms per signal
+    for _ in range(3):
+        rp = _encode(xs, D, '1', monkeypatch, **kw)
+        assert rp.variant.endswith('_rp')
+        _same(rp, seq, B)
