@@ -10,6 +10,7 @@
 #include "hscmp_mfma.h"
 #include "hscmp_sparse.h"
 #include "hscmp_rp.h"
+#include "hscmp_rp_sparse.h"
 #include "hscmp_epilogue.h"
 
 #include <cmath>
@@ -533,6 +534,19 @@ template <typename R, bool PACKED> static int launch_iterate_sparse_t(hscmp_ctx*
 
 template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const DevParams& P0)
 {
+    ctx->rp_last = false;
+    if constexpr (sizeof(R) == 8) {
+        // small batches of blocked rounds: the round-parallel loop (hscmp_rp_sparse.h), one wave per atom of the round
+        if (use_rp(P0)) {
+            State<R> S = make_state<R>(ctx);
+            const SparseArgs<R> A = sparse_args<R>(ctx, P0.T, false);
+            if (rp_sparse_launch<R>(ctx->stream, P0, S, A, true) == 0) {
+                if (rp_sparse_launch<R>(ctx->stream, P0, S, A, false) != 0) return fail(ctx, HSCMP_ERR_HIP, "the round-parallel level loop could not be launched");
+                ctx->rp_last = true;
+                return HSCMP_OK;
+            }
+        }
+    }
     size_t lds_packed = 0;
     (void)launch_iterate_sparse_t<R, true>(ctx, P0, true, &lds_packed);
     if (sparse_loop_packed(P0, lds_packed)) return launch_iterate_sparse_t<R, true>(ctx, P0, false, nullptr);
@@ -618,7 +632,7 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
     ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
-                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + (mfi && ctx->rp_last ? std::string("_rp") : mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
+                   "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + ((mfi || spl) && ctx->rp_last ? std::string("_rp") : mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
     return HSCMP_OK;
 }
 

@@ -210,7 +210,6 @@ __global__ __launch_bounds__(kThreads) void table_rows_sparse_kernel(DevParams P
     R* lx = reinterpret_cast<R*>(smem);
     int* lwf = reinterpret_cast<int*>(lx + cap);
     __shared__ int wcount[kWaves];
-    __shared__ int total;
     const int T = P.T, K = P.K, W = P.W, F = P.F, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool reflect = p >= 0;
     const int t = reflect ? p - (W - 1) + (int)blockIdx.x : row0 + (int)blockIdx.x;

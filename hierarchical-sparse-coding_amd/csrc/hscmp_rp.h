@@ -39,7 +39,6 @@ enum { RPF_INTERIOR = 1 };      // candidate flags: the atom's 3W-2 window lies 
 template <typename R, int MAXSEG, int MAXSEL> struct RpShared {
     R seg_score[MAXSEG];
     int seg_t[MAXSEG];
-    unsigned touched[(MAXSEG + 31) / 32];
     // candidates of the round, one per block (:935-937)
     int c_t[MAXSEL]; int c_k[MAXSEL]; R c_c[MAXSEL];
     R c_eb[MAXSEL]; R c_ea[MAXSEL];           // energy of the atom's clipped window before / after its subtraction
@@ -47,10 +46,11 @@ template <typename R, int MAXSEG, int MAXSEL> struct RpShared {
     int c_flag[MAXSEL];
     int idx[2][MAXSEL];                         // index lists of the filters (ping-pong)
     int ord[MAXSEL];                            // the round's atoms in application order
-    int p_si[MAXSEL]; int p_ev[MAXSEL];       // plan of the prefix: slot (bit 31: new) and event index, per ordered position
+
     int wtot[kRpWaves];
     // control block (written by thread 0, read by all behind a barrier)
-    int converged, stop, napply;
+    int converged, stop, napply, gend;
+    int n, spaced, nedge, full;   // the round's atom count; pairwise >= W apart; atoms at a signal end; event list too short
     int nnz, ndup, rounds, iters, nev, nslots, offset;
     R e_sig, e_res;
 };
@@ -70,17 +70,256 @@ template <typename SH> __device__ __forceinline__ int rp_compact(SH& sh, bool ke
     return total;
 }
 
+// arg-max of the per-position best over [t0, t1) by one wave, t1 - t0 <= 256: the (up to four) loads of a lane are issued
+// together -- one memory round trip, where a load / compare loop makes one per 64 positions.  Same result as
+// wave_range_argmax (maximum score, lowest position among equals).
+template <bool SO, typename R>
+__device__ __forceinline__ Cand<R> rp_range_argmax4(const Sig<R>& G, const R* w, int t0, int t1, int lane)
+{
+    R sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = t0 + lane + 64 * u;
+        sc[u] = (R)-1;
+        if (t < t1) { if constexpr (SO) sc[u] = G.bc[t]; else sc[u] = score_of(G.bc[t], G.bk[t], w); }
+    }
+    Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                       // ascending position per lane: '>' keeps the first of equals
+        const int t = t0 + lane + 64 * u;
+        if (t < t1 && sc[u] > best.s) { best.s = sc[u]; best.i = t; }
+    }
+    return wave_argmax(best);
+}
+
 // segment maximum of the per-position best (score, first position) by one wave
 template <bool SO, typename R, typename SH>
 __device__ __forceinline__ void rp_scan_segment(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
 {
     const int t0 = (sg << P.seg_shift);
     const int t1 = min(P.T, t0 + P.seg);
-    Cand<R> win = wave_range_argmax<SO>(G, w, t0, t1, lane);
+    Cand<R> win = P.seg <= 256 ? rp_range_argmax4<SO>(G, w, t0, t1, lane) : wave_range_argmax<SO>(G, w, t0, t1, lane);
     if (lane == 0) {
         if (win.i == INT_MAX) { win.i = t0; win.s = (R)0; }
         sh.seg_score[sg] = win.s;
         sh.seg_t[sg] = win.i;
+    }
+}
+
+// arg-max of the per-position best over the block [lo, hi) by one wave through the segment maxima (wave_block_argmax of
+// hscmp_kernels.h), the two ragged ends -- less than a segment each -- fetched in ONE batch of loads.
+template <bool SO, typename R, typename SH>
+__device__ __forceinline__ Cand<R> rp_block_argmax(const DevParams& P, const Sig<R>& G, const R* w, const SH& sh, int lo, int hi, int lane)
+{
+    const int sgA = (lo + P.seg - 1) >> P.seg_shift;                        // first segment entirely inside
+    const int sgB = (hi >= P.T) ? P.nseg - 1 : (hi >> P.seg_shift) - 1;     // last one (the last segment of the signal may be short)
+    if (P.seg > 128 || sgA > sgB) return wave_block_argmax<SO>(P, G, w, sh, lo, hi, lane);
+    const int headEnd = sgA << P.seg_shift, tailBegin = min(hi, (sgB + 1) << P.seg_shift);
+    R hs[2], ts[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int th = lo + lane + 64 * u, tt = tailBegin + lane + 64 * u;
+        hs[u] = (R)-1; ts[u] = (R)-1;
+        if (th < headEnd) { if constexpr (SO) hs[u] = G.bc[th]; else hs[u] = score_of(G.bc[th], G.bk[th], w); }
+        if (tt < hi) { if constexpr (SO) ts[u] = G.bc[tt]; else ts[u] = score_of(G.bc[tt], G.bk[tt], w); }
+    }
+    Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+    // per lane the candidates come in ascending position, so '>' keeps the first of equals
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int th = lo + lane + 64 * u; if (th < headEnd && hs[u] > best.s) { best.s = hs[u]; best.i = th; } }
+    for (int sg = sgA + lane; sg <= sgB; sg += 64) {
+        const R sc = sh.seg_score[sg];
+        if (sc > best.s) { best.s = sc; best.i = sh.seg_t[sg]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int tt = tailBegin + lane + 64 * u; if (tt < hi && ts[u] > best.s) { best.s = ts[u]; best.i = tt; } }
+    return wave_argmax(best);
+}
+
+// ---- P2 by the whole workgroup (more than 64 blocks: nbBlocks='auto' on long signals): index lists in LDS --------
+template <typename R, typename SH>
+__device__ __forceinline__ void rp_block_select(const DevParams& P, SH& sh, int nb)
+{
+    const int tid = threadIdx.x, T = P.T, W = P.W, F = P.F;
+    const bool has_thres = P.has_thres != 0;
+    const double thres = P.thres;
+    constexpr int MAXSEL = (int)(sizeof(sh.ord) / sizeof(int));
+    int* la = sh.idx[0]; int* lb = sh.idx[1];
+    bool spaced = true;
+    // :946-948 drop null coefficients (and invalid blocks)
+    int n = rp_compact(sh, tid < nb && sh.c_t[tid] >= 0 && (!has_thres || fabs((double)sh.c_c[tid]) > thres), tid, la);
+    // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
+    if (n > 1) {
+        const bool gap = tid >= 1 && tid < n && (sh.c_t[la[tid]] - sh.c_t[la[tid - 1]] >= W);
+        if (__syncthreads_or(gap ? 1 : 0)) {
+            n = rp_compact(sh, tid < n && (tid == 0 || gap), tid < n ? la[tid] : 0, lb);
+            int* tmp = la; la = lb; lb = tmp;
+        } else {
+            spaced = false;
+        }
+    }
+    // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals (rank sort)
+    if (tid < n) {
+        const int me = la[tid];
+        const R a = rabs(sh.c_c[me]);
+        int rank = 0;
+        for (int q = 0; q < n; ++q) {
+            const R o = rabs(sh.c_c[la[q]]);
+            rank += (o > a || (o == a && q > tid)) ? 1 : 0;
+        }
+        lb[rank] = me;
+    }
+    __syncthreads();
+    { int* tmp = la; la = lb; lb = tmp; }
+    // :1090-1099 weak-atom filter: the window of the filter is the atom's clipped support, its energy c_eb
+    if (P.has_snr && n > 1) {
+        const R tol_energy = sh.e_sig / (R)P.snr_ratio;
+        const double thr = (double)tol_energy / (double)((int64_t)T * F);
+        bool keep = false;
+        if (tid < n) {
+            const int me = la[tid];
+            int s, e, es;
+            const int len = centered_span(T, W, sh.c_t[me], s, e, es);
+            const R mean = sh.c_eb[me] / (R)((int64_t)len * F);
+            keep = (double)mean >= thr;
+        }
+        n = rp_compact(sh, keep, tid < MAXSEL ? la[tid] : 0, lb);
+        int* tmp = la; la = lb; lb = tmp;
+    }
+    if (tid < n) sh.ord[tid] = la[tid];
+    const int nedge = __syncthreads_count((tid < n && !(sh.c_flag[sh.ord[tid]] & RPF_INTERIOR)) ? 1 : 0);
+    if (tid == 0) { sh.n = n; sh.spaced = spaced ? 1 : 0; sh.nedge = nedge; }
+    __syncthreads();
+}
+
+// ---- P2 by ONE wave (at most 64 blocks): candidate j in lane j, compactions through a strip of LDS (the LDS executes
+//      a wave's operations in order: no barrier), the |c| order by a rank sort over v_readlane broadcasts ------------
+template <typename R, typename SH>
+__device__ __forceinline__ void rp_wave_select(const DevParams& P, SH& sh, int nb, int lane)
+{
+    const int T = P.T, W = P.W, F = P.F;
+    int* strip = sh.idx[0];
+    auto fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    // lanes holding `keep` move to the front, in lane order; returns their number
+    auto compact = [&](bool keep, int& me) {
+        const unsigned long long mask = __ballot(keep);
+        if (keep) strip[__popcll(mask & ((1ull << lane) - 1ull))] = me;
+        fence();
+        const int cnt = __popcll(mask);
+        me = lane < cnt ? strip[lane] : 0;
+        fence();
+        return cnt;
+    };
+    int me = lane;
+    // :946-948 drop null coefficients (and invalid blocks)
+    bool keep = lane < nb && sh.c_t[lane] >= 0 && (P.has_thres == 0 || fabs((double)sh.c_c[lane]) > P.thres);
+    int n = compact(keep, me);
+    bool spaced = true;
+    // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
+    if (n > 1) {
+        const int t = lane < n ? sh.c_t[me] : 0;
+        const int tp = __shfl_up(t, 1);
+        const bool gap = lane >= 1 && lane < n && (t - tp >= W);
+        if (__ballot(gap) != 0ull) n = compact(lane < n && (lane == 0 || gap), me);
+        else spaced = false;
+    }
+    // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals
+    if (n > 1) {
+        const R a = lane < n ? rabs(sh.c_c[me]) : (R)0;
+        int rank = 0;
+        for (int q = 0; q < n; ++q) {
+            const R o = wave_bcast(a, q);
+            rank += (o > a || (o == a && q > lane)) ? 1 : 0;
+        }
+        if (lane < n) strip[rank] = me;
+        fence();
+        me = lane < n ? strip[lane] : 0;
+        fence();
+    }
+    // :1090-1099 weak-atom filter: the window of the filter is the atom's clipped support, its energy c_eb
+    if (P.has_snr && n > 1) {
+        const R tol_energy = sh.e_sig / (R)P.snr_ratio;
+        const double thr = (double)tol_energy / (double)((int64_t)T * F);
+        keep = false;
+        if (lane < n) {
+            int s, e, es;
+            const int len = centered_span(T, W, sh.c_t[me], s, e, es);
+            const R mean = sh.c_eb[me] / (R)((int64_t)len * F);
+            keep = (double)mean >= thr;
+        }
+        n = compact(keep, me);
+    }
+    const unsigned long long edges = __ballot(lane < n && !(sh.c_flag[me] & RPF_INTERIOR));
+    if (lane < n) sh.ord[lane] = me;
+    if (lane == 0) { sh.n = n; sh.spaced = spaced ? 1 : 0; sh.nedge = __popcll(edges); }
+}
+
+// ---- P3 by ONE wave: bookkeeping (:1106-1114) and the fast stop rules (:1125-1142) of the atoms ord[pos, gend) in
+//      selection order, 64 atoms at a time, atom i in lane i.  The counters are prefix popcounts; the residual energy is
+//      the same chain of subtractions (:1014), carried through v_readlane; every lane tests the stop rules of its own atom
+//      and the first lane that stops cuts the group.  The lanes of the applied atoms write their slots and events. ------
+struct RpPending { int t, k, si, ev, fresh, on; double a; };
+template <typename R> __device__ __forceinline__ void rp_store_pending(const DevParams& P, const Sig<R>& G, const RpPending& q, R c)
+{
+    if (!q.on) return;
+    if (q.fresh) { G.slot_t[q.si] = q.t; G.slot_k[q.si] = q.k; slot_insert(G, P.hmask, q.t, q.k, q.si); }
+    G.slot_a[q.si] = q.a;
+    G.ev_t[q.ev] = q.t; G.ev_k[q.ev] = q.k; G.ev_c[q.ev] = c;
+}
+// (the slot / event stores of the LAST chunk are handed back: the caller issues them behind the workgroup barrier, where
+//  the other waves are already at work -- the compare-and-swap of a table insert is a memory round trip)
+template <typename R, typename SH>
+__device__ __forceinline__ void rp_wave_prefix(const DevParams& P, SH& sh, const Sig<R>& G, int pos, int gend, int lane, RpPending& pend, R& pend_c)
+{
+    pend.on = 0; pend_c = (R)0;
+    int nnz = sh.nnz, ndup = sh.ndup, nslots = sh.nslots, nev = sh.nev, iters = sh.iters;
+    R e_res = sh.e_res;
+    const R e_sig = sh.e_sig;
+    int conv = 0, stop = STOP_RUNNING, applied_end = gend;
+    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    for (int base = pos; base < gend && !conv; base += 64) {
+        const int cnt = min(64, gend - base);
+        const bool on = lane < cnt;
+        const int me = on ? sh.ord[base + lane] : 0;
+        const R c = sh.c_c[me];
+        const int found = sh.c_found[me];
+        const double acc = sh.c_acc[me];
+        const R loss = on ? sh.c_eb[me] - sh.c_ea[me] : (R)0;        // :1005
+        const bool is_dup = on && found >= 0 && fabs(acc) > 0.0;
+        const bool is_nnz = on && !is_dup && rabs(c) > (R)0;
+        const bool fresh = on && found < 0;
+        const unsigned long long m_nnz = __ballot(is_nnz), m_dup = __ballot(is_dup), m_fresh = __ballot(fresh);
+        R cur = e_res, mine = (R)0;
+        for (int j = 0; j < cnt; ++j) {                              // :1014, atom after atom
+            cur = cur - wave_bcast(loss, j);
+            if (lane == j) mine = cur;
+        }
+        const int nnz_i = nnz + __popcll(m_nnz & le);
+        int st = STOP_RUNNING;
+        if (on) {
+            if ((double)mine < P.eps) st = STOP_ENERGY_EPS;
+            else if (P.l0 >= 0 && nnz_i >= P.l0) st = STOP_NNZ;
+            else if (P.has_snr) {
+                const R q = e_sig / mine;
+                if ((double)q >= P.snr_ratio) st = STOP_SNR;
+            }
+        }
+        const unsigned long long ms = __ballot(st != STOP_RUNNING);
+        const int take = ms ? __ffsll((long long)ms) : cnt;          // atoms of this chunk that are applied
+        const unsigned long long below = take >= 64 ? ~0ull : ((1ull << take) - 1ull);
+        // coefficient slot and event of the atom (:1114; :992: a new accumulator starts at 0.0)
+        pend.on = lane < take; pend.t = sh.c_t[me]; pend.k = sh.c_k[me]; pend.fresh = fresh;
+        pend.si = fresh ? nslots + __popcll(m_fresh & lt) : found; pend.ev = nev + lane; pend.a = acc + (double)c; pend_c = c;
+        if (!ms && base + 64 < gend) { rp_store_pending<R>(P, G, pend, pend_c); pend.on = 0; }
+        nnz += __popcll(m_nnz & below); ndup += __popcll(m_dup & below); nslots += __popcll(m_fresh & below);
+        nev += take; iters += take;
+        e_res = wave_bcast(mine, take - 1);
+        if (ms) { conv = 1; stop = __builtin_amdgcn_readlane(st, take - 1); applied_end = base + take; }
+    }
+    if (lane == 0) {
+        sh.nnz = nnz; sh.ndup = ndup; sh.nslots = nslots; sh.nev = nev; sh.iters = iters; sh.e_res = e_res;
+        if (conv) { sh.converged = 1; sh.stop = stop; }
+        sh.napply = applied_end; sh.gend = gend;
     }
 }
 
@@ -93,7 +332,6 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using SH = typename Pol::Shared;
-    constexpr int MAXSEL = Pol::kMaxSel;
     SH& sh = *reinterpret_cast<SH*>(smem);
     char* plds = smem + ((sizeof(SH) + 15) / 16) * 16;
     const int b = blockIdx.x;
@@ -112,17 +350,17 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
     G.sel_t = nullptr; G.sel_k = nullptr; G.sel_c = nullptr;
 
     Pol::prologue(P, S, G, A, plds, b);                  // (ends with a workgroup barrier)
+    const int nteams = Pol::teams(A);                    // waves that take per-atom work (each needs a strip of LDS)
     const R* wts = Pol::weights(P, S, A, plds);
 
     // ---- segment maxima; the (t,k) -> slot table of this launch, from the slot list (always on: the probes of a
     //      round go out side by side, one per candidate)
     for (int sg = wv; sg < P.nseg; sg += kRpWaves) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
     for (unsigned i = tid; i <= P.hmask; i += kRpThreads) hkey_store(G.hkey + i, kSlotEmpty);
-    for (int i = tid; i < (Pol::kMaxSegments + 31) / 32; i += kRpThreads) sh.touched[i] = 0u;
     if (tid == 0) {
         sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
-        sh.converged = 0; sh.stop = STOP_RUNNING; sh.napply = 0;
+        sh.converged = 0; sh.stop = STOP_RUNNING; sh.napply = 0; sh.gend = 0; sh.n = 0; sh.spaced = 1; sh.nedge = 0; sh.full = 0;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
     }
     __syncthreads();
@@ -132,8 +370,6 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
     }
     __syncthreads();
 
-    const double thres = P.thres;
-    const bool has_thres = P.has_thres != 0;
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
         HSCMP_STAMP(16);                                                      // round end of the previous round
@@ -141,12 +377,13 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
         const int off = sh.offset;
         const int nb = P.nbk + (off ? 1 : 0);
         const int pad0 = off ? P.bs / 2 : 0;
-        for (int j = wv; j < nb; j += kRpWaves) {
+        for (int j = wv; j < nb && wv < nteams; j += nteams) {
             const int w0 = j * P.bs - pad0;
             const int lo = w0 < 0 ? 0 : w0;
             const int hi = min(T, w0 + P.bs);
             Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
-            if (lo < hi) win = wave_block_argmax<Pol::kScoreOnly>(P, G, wts, sh, lo, hi, lane);
+            if (lo < hi) win = rp_block_argmax<Pol::kScoreOnly>(P, G, wts, sh, lo, hi, lane);
+            HSCMP_STAMP(25);
             bool valid = (lo < hi) && win.i != INT_MAX;                      // :940-942 range test
             if (valid && win.s == (R)0 && w0 < 0) valid = false;             // arg-max on a leading padded row
             int wk = 0, flag = 0, found = -1;
@@ -154,11 +391,13 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
             double acc = 0.0;
             if (valid) {                                                     // wave-uniform
                 Pol::candidate(P, S, G, A, plds, win.i, lane, wv, wk, wc, eb, ea, flag);
+                HSCMP_STAMP(26);
                 if (lane == 0) {
                     unsigned pos;
                     found = slot_find(G, P.hmask, win.i, wk, pos);
                     if (found >= 0) acc = G.slot_a[found];
                 }
+                HSCMP_STAMP(27);
             }
             if (lane == 0) {
                 sh.c_t[j] = valid ? win.i : -1; sh.c_k[j] = wk; sh.c_c[j] = wc; sh.c_eb[j] = eb; sh.c_ea[j] = ea;
@@ -168,127 +407,59 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
         __syncthreads();
         HSCMP_STAMP(17);                                                      // block arg-max + candidates
         // =========================== P2: filters and order (:946-962, :1090-1099) ===========================
-        int n;
-        bool spaced = true;                                                  // the atoms of the round are pairwise >= W apart
-        {
-            int* la = sh.idx[0]; int* lb = sh.idx[1];
-            // :946-948 drop null coefficients (and invalid blocks)
-            n = rp_compact(sh, tid < nb && sh.c_t[tid] >= 0 && (!has_thres || fabs((double)sh.c_c[tid]) > thres), tid, la);
-            // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
-            if (n > 1) {
-                const bool gap = tid >= 1 && tid < n && (sh.c_t[la[tid]] - sh.c_t[la[tid - 1]] >= W);
-                if (__syncthreads_or(gap ? 1 : 0)) {
-                    n = rp_compact(sh, tid < n && (tid == 0 || gap), tid < n ? la[tid] : 0, lb);
-                    int* tmp = la; la = lb; lb = tmp;
-                } else {
-                    spaced = false;
-                }
-            }
-            // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals (rank sort)
-            if (tid < n) {
-                const int me = la[tid];
-                const R a = rabs(sh.c_c[me]);
-                int rank = 0;
-                for (int q = 0; q < n; ++q) {
-                    const R o = rabs(sh.c_c[la[q]]);
-                    rank += (o > a || (o == a && q > tid)) ? 1 : 0;
-                }
-                lb[rank] = me;
-            }
-            __syncthreads();
-            { int* tmp = la; la = lb; lb = tmp; }
-            // :1090-1099 weak-atom filter: the window of the filter is the atom's clipped support, its energy c_eb
-            if (P.has_snr && n > 1) {
-                const R tol_energy = sh.e_sig / (R)P.snr_ratio;
-                const double thr = (double)tol_energy / (double)((int64_t)T * F);
-                bool keep = false;
-                if (tid < n) {
-                    const int me = la[tid];
-                    int s, e, es;
-                    const int len = centered_span(T, W, sh.c_t[me], s, e, es);
-                    const R mean = sh.c_eb[me] / (R)((int64_t)len * F);
-                    keep = (double)mean >= thr;
-                }
-                n = rp_compact(sh, keep, tid < MAXSEL ? la[tid] : 0, lb);
-                int* tmp = la; la = lb; lb = tmp;
-            }
-            if (tid < n) sh.ord[tid] = la[tid];
-        }
-        // atoms that form a group of their own (signal ends); uniform
-        const int nedge = __syncthreads_count((tid < n && !(sh.c_flag[sh.ord[tid]] & RPF_INTERIOR)) ? 1 : 0);
-        HSCMP_STAMP(18);                                                      // filters + sort
-        // A round whose atoms do not all fit the event list is not started: the state then is exactly that of a round
-        // boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
-        if (sh.nev + n > P.cap) {                                            // uniform (LDS, behind a barrier)
-            __syncthreads();
-            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; }
-            break;
-        }
+        // Up to 64 blocks: wave 0 alone, candidates in its lanes (no workgroup barrier until the atoms are known AND the
+        // bookkeeping prefix of the first group is done); more blocks: the whole workgroup over index lists.
+        const bool small = nb <= 64;
+        if (!small) rp_block_select<R>(P, sh, nb);                           // (ends with a barrier)
         // =========================== P3-P5: apply the atoms (:1101-1142), group by group ===========================
-        int pos = 0;
-        while (pos < n) {
-            int gend;
-            if (!spaced) {
-                // overlapping atoms: one at a time, energies as of its turn
-                gend = pos + 1;
-                if (pos > 0) {
-                    if (wv == 0) {
-                        const int me = sh.ord[pos];
-                        R eb, ea;
-                        Pol::energies(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv, eb, ea);
-                        if (lane == 0) { sh.c_eb[me] = eb; sh.c_ea[me] = ea; }
+        int pos = 0, n = 0;
+        bool full = false;
+        for (;;) {
+            RpPending pend; pend.on = 0;
+            R pend_c = (R)0;
+            if (wv == 0) {
+                if (pos == 0 && small) rp_wave_select<R>(P, sh, nb, lane);
+                HSCMP_STAMP(23);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int nn = sh.n;
+                // A round whose atoms do not all fit the event list is not started: the state then is exactly that of a
+                // round boundary, and hscmp_grow_events + hscmp_continue resume bit for bit.
+                if (pos == 0 && sh.nev + nn > P.cap) { if (lane == 0) sh.full = 1; }
+                else if (pos < nn) {
+                    int gend;
+                    if (!sh.spaced) {
+                        // overlapping atoms: one at a time, energies as of its turn
+                        gend = pos + 1;
+                        if (pos > 0) {
+                            const int me = sh.ord[pos];
+                            R eb, ea;
+                            Pol::energies(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv, eb, ea);
+                            if (lane == 0) { sh.c_eb[me] = eb; sh.c_ea[me] = ea; }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    } else if (sh.nedge == 0) {
+                        gend = nn;
+                    } else if (!(sh.c_flag[sh.ord[pos]] & RPF_INTERIOR)) {
+                        gend = pos + 1;                                      // an atom at a signal end: alone
+                    } else {
+                        gend = pos + 1;
+                        while (gend < nn && (sh.c_flag[sh.ord[gend]] & RPF_INTERIOR)) ++gend;
                     }
-                    __syncthreads();
+                    rp_wave_prefix<R>(P, sh, G, pos, gend, lane, pend, pend_c);   // (-> sh.napply, sh.gend, sh.converged / sh.stop)
+                    HSCMP_STAMP(24);
                 }
-            } else if (nedge == 0) {
-                gend = n;
-            } else if (!(sh.c_flag[sh.ord[pos]] & RPF_INTERIOR)) {
-                gend = pos + 1;
-            } else {
-                gend = pos + 1;
-                while (gend < n && (sh.c_flag[sh.ord[gend]] & RPF_INTERIOR)) ++gend;
-            }
-            // ---- P3: bookkeeping and fast stop rules of the group in selection order (:1106-1142)
-            if (tid == 0) {
-                int i = pos;
-                for (; i < gend; ++i) {
-                    const int me = sh.ord[i];
-                    const R c = sh.c_c[me];
-                    int si = sh.c_found[me];
-                    if (si >= 0 && fabs(sh.c_acc[me]) > 0.0) sh.ndup += 1;
-                    else if (rabs(c) > (R)0) sh.nnz += 1;
-                    const bool fresh = si < 0;
-                    if (fresh) si = sh.nslots++;
-                    sh.p_si[i] = si | (fresh ? (int)0x80000000 : 0);
-                    sh.p_ev[i] = sh.nev++;
-                    const R loss = sh.c_eb[me] - sh.c_ea[me];            // :1005
-                    sh.e_res = sh.e_res - loss;                          // :1014
-                    sh.iters += 1;
-                    if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
-                    else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
-                    else if (P.has_snr) {
-                        const R q = sh.e_sig / sh.e_res;
-                        if ((double)q >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; }
-                    }
-                    if (sh.converged) { ++i; break; }
-                }
-                sh.napply = i;
             }
             __syncthreads();
-            const int aend = sh.napply;
-            HSCMP_STAMP(19);                                                  // prefix
-            // coefficient slots and events of the applied atoms (:1114), one thread per atom
-            if (tid >= pos && tid < aend) {
-                const int me = sh.ord[tid];
-                const int t = sh.c_t[me], k = sh.c_k[me];
-                const R c = sh.c_c[me];
-                const int si = sh.p_si[tid] & 0x7fffffff, ev = sh.p_ev[tid];
-                if (sh.p_si[tid] < 0) { G.slot_t[si] = t; G.slot_k[si] = k; slot_insert(G, P.hmask, t, k, si); }
-                G.slot_a[si] = sh.c_acc[me] + (double)c;                     // (:992: a new accumulator starts at 0.0)
-                G.ev_t[ev] = t; G.ev_k[ev] = k; G.ev_c[ev] = c;
-            }
+            if (wv == 0) rp_store_pending<R>(P, G, pend, pend_c);
+            n = sh.n;
+            if (sh.full) { full = true; break; }
+            if (pos >= n) break;
+            const int aend = sh.napply, gend = sh.gend;
+            HSCMP_STAMP(18);                                                  // filters + order + prefix
             // ---- P4: residual subtraction (:1117, :996-1016), one wave per atom
-            for (int i = pos + wv; i < aend; i += kRpWaves) {
+            for (int i = pos + wv; i < aend && wv < nteams; i += nteams) {
                 const int me = sh.ord[i];
                 Pol::subtract(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv);
             }
@@ -298,57 +469,49 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
             {
                 const int upa = Pol::units_per_atom(P);
                 const int nu = (aend - pos) * upa;
-                for (int u = wv; u < nu; u += kRpWaves) {
+                for (int u = wv; u < nu && wv < nteams; u += nteams) {
                     const int a = u / upa, q = u - a * upa;
                     const int me = sh.ord[pos + a];
                     const int p = sh.c_t[me];
                     Pol::recorrelate(P, S, G, A, plds, p, sh.c_k[me], q, (sh.c_flag[me] & RPF_INTERIOR) != 0, lane, wv);
-                    if (q == 0 && lane == 0) {
-                        const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
-                        for (int sg = lo >> P.seg_shift; sg <= (hi >> P.seg_shift); ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
-                    }
                 }
             }
             __syncthreads();
             HSCMP_STAMP(21);                                                  // re-correlation
-            if (nedge > 0 || !spaced) {
-                if (tid == 0)
-                    for (int i = pos; i < aend; ++i) {
-                        const int me = sh.ord[i];
-                        if (!(sh.c_flag[me] & RPF_INTERIOR)) Pol::after_atom(P, A, plds, sh.c_t[me]);
-                    }
-                __syncthreads();
-            }
+            // (edge history of atoms at a signal end: read next by wave 0 -- in order behind this -- or behind a later barrier)
+            if ((sh.nedge > 0 || !sh.spaced) && tid == 0)
+                for (int i = pos; i < aend; ++i) {
+                    const int me = sh.ord[i];
+                    if (!(sh.c_flag[me] & RPF_INTERIOR)) Pol::after_atom(P, A, plds, sh.c_t[me]);
+                }
             if (sh.converged) break;
             pos = gend;
         }
+        if (full) {
+            if (tid == 0) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.full = 0; }
+            break;
+        }
         // =========================== P6: segment maxima, slow stop rules (:1145-1163) ===========================
         if (n > 0 && !sh.converged) {
-            // every wave walks the set bits (lane l holds word l) and takes every 16th touched segment
-            constexpr int kWords = (Pol::kMaxSegments + 31) / 32;
-            static_assert(kWords <= 64, "one mask word per lane");
-            const unsigned word = lane < kWords ? sh.touched[lane] : 0u;
-            unsigned long long words = __ballot(word != 0u);
-            int r = 0;
-            while (words) {                                                  // wave-uniform
-                const int wl = __ffsll((long long)words) - 1;
-                words &= words - 1ull;
-                unsigned bits = __shfl(word, wl);
-                while (bits) {
-                    const int sg = wl * 32 + __ffs((int)bits) - 1;
-                    bits &= bits - 1u;
-                    if (((r++) & (kRpWaves - 1)) != wv) continue;
-                    rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
-                }
+            // the segments that the rows of the applied atoms lie in, one wave per (atom, segment); a segment that two atoms
+            // share is scanned twice, with the same result
+            const int mps = ((2 * W - 2) >> P.seg_shift) + 2;               // segments an atom's 2W-1 rows can touch
+            const int nu = sh.napply * mps;                                  // (the groups of a round are consecutive: ord[0, napply))
+            for (int u = wv; u < nu; u += kRpWaves) {
+                const int a = u / mps, q = u - a * mps;
+                const int p = sh.c_t[sh.ord[a]];
+                const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
+                const int sg = (lo >> P.seg_shift) + q;
+                if (sg <= (hi >> P.seg_shift)) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
             }
         }
+        HSCMP_STAMP(28);
         if (tid == 0) {
             if (n == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }     // :1150-1153
             sh.rounds += 1;
             sh.offset = !sh.offset;
         }
         __syncthreads();
-        if (tid < (Pol::kMaxSegments + 31) / 32) sh.touched[tid] = 0u;      // (next marked several barriers from here)
         HSCMP_STAMP(22);                                                      // segment maxima + round end
 #ifdef HSCMP_DBG_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[30] += 1; g_stamps[31] += (unsigned long long)n; }
@@ -402,6 +565,7 @@ template <int S4C, bool HAS_W> struct RpMfma {
     }
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
     static __device__ __forceinline__ int units_per_atom(const DevParams& P) { return (2 * P.W - 1 + TP - 1) / TP; }
+    static __device__ __forceinline__ int teams(const Args&) { return kRpWaves; }
 
     static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Sig<R>&, const Args& A, char* lds, int b)
     {

@@ -118,3 +118,58 @@ def test_config5_level0_dims_three_runs(monkeypatch):
         rp = _encode(xs, D, '1', monkeypatch, **kw)
         assert rp.variant.endswith('_rp')
         _same(rp, seq, B)
+
+
+def _level_problem(seed, W, F, K, T, dense_rows=0):
+    """A level >= 1 shaped problem (sparse input rows, sparse dictionary with singleton atoms in front), float64."""
+    rs = np.random.RandomState(seed)
+    D = np.zeros((K, W, F))
+    for k in range(K):
+        for _ in range(int(rs.randint(1, 6))):
+            D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+        D[k] /= np.sqrt(np.sum(np.square(D[k])))
+    S = np.zeros((F, W, F)); S[np.arange(F), (W - 1) // 2, np.arange(F)] = 1.0
+    D = np.concatenate((S, D), axis=0)
+    x = np.zeros((T, F))
+    for _ in range(int(rs.randint(T // 12, T // 4))):
+        x[rs.randint(0, T), rs.randint(0, F)] = rs.uniform(0.3, 2.0) * rs.choice([-1.0, 1.0])
+    for t in rs.randint(0, T, size=dense_rows):
+        n = min(F, int(rs.randint(9, 30)))
+        x[t, rs.permutation(F)[:n]] = rs.standard_normal(n)            # a dense-ish row: its feature list overflows
+    w = np.ones(D.shape[0]); w[:F] = rs.uniform(0.7, 0.95)
+    return x, D, w
+
+
+LEVEL_CASES = [
+    # (W, F, K, T, nbBlocks, dense rows)
+    (16, 48, 20, 1400, 10, 0),
+    (17, 130, 12, 1100, 10, 0),
+    (33, 48, 16, 2000, 10, 0),
+    (65, 130, 10, 1800, 7, 0),
+    (9, 12, 6, 700, 'auto', 0),
+    (16, 48, 20, 1500, 10, 3),
+    (33, 130, 8, 1600, 4, 2),
+    (5, 30, 8, 300, 3, 0),
+]
+
+
+@pytest.mark.parametrize('case', range(len(LEVEL_CASES)))
+def test_level_shaped_round_parallel_vs_sequential_vs_oracle(case, monkeypatch):
+    from oracle import hsc_oracle as orc
+    W, F, K, T, nb, dense = LEVEL_CASES[case]
+    probs = [_level_problem(7000 + 10 * case + i, W, F, K, T, dense) for i in range(3)]
+    D, w = probs[0][1], probs[0][2]
+    xs = np.stack([p[0] for p in probs])
+    xs[1, :W] *= 3.0; xs[2, -W:] *= 3.0                          # atoms at the signal ends
+    kw = dict(toleranceSnr=22.0, nbNonzeroCoefs=400, nbBlocks=nb, weights=w, minCoefficients=None)
+    rp = _encode(xs, D, '1', monkeypatch, **kw)
+    assert rp.variant.endswith('_rp'), rp.variant
+    seq = _encode(xs, D, '0', monkeypatch, **kw)
+    assert not seq.variant.endswith('_rp'), seq.variant
+    _same(rp, seq, xs.shape[0])
+    coef, r, info = orc.cmp_encode(xs[1], D, maxEvents=2000, **kw)
+    if info['stop'] != 'capacity':
+        t, k, c = rp.events[1]
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), case
+        assert np.array_equal(rp.residuals[1], r), case
+        assert rp.stop_reasons()[1] == info['stop']

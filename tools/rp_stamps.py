@@ -22,8 +22,8 @@ for tm in timings:
     print('level %d: %-34s prepare %.2f init %.2f loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][0], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
 rounds, atoms = max(v[30], 1), max(v[31], 1)
 print('round-parallel loops of workgroup 0 (all levels that ran it): %d rounds, %d atoms (%.1f per round)' % (rounds, atoms, atoms / rounds))
-names = {16: 'top of round', 17: 'P1 block arg-max + candidates', 18: 'P2 filters + order', 19: 'P3 prefix', 20: 'P4 bookkeeping stores + subtraction',
-         21: 'P5 re-correlation', 22: 'P6 segment maxima + round end', 23: '-', 24: '-', 25: '-', 26: '-', 27: '-', 28: '-', 29: '-'}
+names = {16: 'top of round', 17: 'P1 rest (wait for the other waves)', 18: 'P2/P3 rest (barrier)', 19: 'P3 prefix', 20: 'P4 bookkeeping stores + subtraction',
+         21: 'P5 re-correlation', 22: 'P6 rest (barriers, round end)', 23: '  wave 0: filters + order', 24: '  wave 0: prefix', 25: '  wave 0: block arg-max', 26: '  wave 0: candidate (resolve + energies)', 27: '  wave 0: slot lookup', 28: '  wave 0: segment scans', 29: '-'}
 tot = 0.0
 for i in range(16, 30):
     if v[i] > 0:
