@@ -263,6 +263,7 @@ template <typename R> struct State {
     int* stats;         // [B][ST_COUNT]
     R* energy;          // [B][2]: signal, residual
     unsigned long long* edge;   // [B][kEdgeWords]: edge rows re-correlated at least once + the stale-sample record (score-only policies)
+    int* head;          // [B][T] round-parallel loop: most recent coefficient slot at position t (-1: none), chained through hval
 };
 
 __device__ __forceinline__ float rabs(float v) { return fabsf(v); }

@@ -491,6 +491,7 @@ template <typename R> struct Sig {   // per-signal views
     int* slot_t; int* slot_k; double* slot_a;
     unsigned long long* hkey; int* hval;
     int* sel_t; int* sel_k; R* sel_c;
+    int* head;          // (round-parallel loop only)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
+    G.head = S.head;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
         g_blk[3 * b + 0] = wall_clock64();

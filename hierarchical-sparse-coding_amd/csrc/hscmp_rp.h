@@ -44,6 +44,7 @@ template <typename R, int MAXSEG, int MAXSEL> struct RpShared {
     R c_eb[MAXSEL]; R c_ea[MAXSEL];           // energy of the atom's clipped window before / after its subtraction
     int c_found[MAXSEL]; double c_acc[MAXSEL];  // coefficient slot of (t, k) as of the round start (-1: none) and its accumulator
     int c_flag[MAXSEL];
+    int c_head[MAXSEL];                         // first link of the position's slot chain as of the round start
     int idx[2][MAXSEL];                         // index lists of the filters (ping-pong)
     int ord[MAXSEL];                            // the round's atoms in application order
 
@@ -70,6 +71,66 @@ template <typename SH> __device__ __forceinline__ int rp_compact(SH& sh, bool ke
     return total;
 }
 
+// ---- wave reductions on the vector ALU for float64 (the generic forms of hscmp_device.h go through ds_bpermute: two to
+//      three LDS-crossbar operations per step and value) ------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)          // result in every lane (wave-uniform)
+{
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// (score, index) arg-max as wave_argmax: larger score, then the smaller index.  Scores are >= 0 (or -1 for "nothing"): their
+// bit patterns order like the values (the sentinel is negative as an integer), so the maximum is taken word by word.
+template <typename R> __device__ __forceinline__ Cand<R> rp_wave_argmax(Cand<R> c) { return wave_argmax(c); }
+template <> __device__ __forceinline__ Cand<double> rp_wave_argmax<double>(Cand<double> c)
+{
+    const long long bits = __double_as_longlong(c.s);
+    const int hi = (int)(bits >> 32);
+    const unsigned lo = (unsigned)bits;
+    const int mh = wave_max_i32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    Cand<double> r;
+    r.s = __longlong_as_double(((long long)mh << 32) | (long long)ml);
+    r.i = wave_min_i32((hi == mh && lo == ml) ? c.i : INT_MAX);
+    return r;
+}
+// halving tree of the pinned sums (wave_tree_down2 of hscmp_device.h: lane i += lane i+m for m = 32 .. 1, total in lane 0)
+// for float64: the partner's two words come through v_permlane32_swap / v_permlane16_swap and row_shl DPP moves
+__device__ __forceinline__ void rp_tree_down2(float& a, float& b) { wave_tree_down2(a, b); }
+__device__ __forceinline__ void rp_tree_down2(double& a, double& b)
+{
+    auto partner32 = [](double v) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        return __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    auto partner16 = [](double v) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        return __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    { const double oa = partner32(a), ob = partner32(b); a = a + oa; b = b + ob; }
+    { const double oa = partner16(a), ob = partner16(b); a = a + oa; b = b + ob; }
+#define HSCMP_RP_TREE_STEP(CTRL)                                                                                               \
+    {                                                                                                                          \
+        const double oa = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, 0xF, 0xF, true),            \
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true));           \
+        const double ob = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(b), CTRL, 0xF, 0xF, true),            \
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(b), CTRL, 0xF, 0xF, true));           \
+        a = a + oa; b = b + ob;                                                                                                \
+    }
+    HSCMP_RP_TREE_STEP(0x108)      // row_shl:8
+    HSCMP_RP_TREE_STEP(0x104)
+    HSCMP_RP_TREE_STEP(0x102)
+    HSCMP_RP_TREE_STEP(0x101)
+#undef HSCMP_RP_TREE_STEP
+}
+
 // arg-max of the per-position best over [t0, t1) by one wave, t1 - t0 <= 256: the (up to four) loads of a lane are issued
 // together -- one memory round trip, where a load / compare loop makes one per 64 positions.  Same result as
 // wave_range_argmax (maximum score, lowest position among equals).
@@ -89,7 +150,7 @@ __device__ __forceinline__ Cand<R> rp_range_argmax4(const Sig<R>& G, const R* w,
         const int t = t0 + lane + 64 * u;
         if (t < t1 && sc[u] > best.s) { best.s = sc[u]; best.i = t; }
     }
-    return wave_argmax(best);
+    return rp_wave_argmax(best);
 }
 
 // segment maximum of the per-position best (score, first position) by one wave
@@ -103,6 +164,37 @@ __device__ __forceinline__ void rp_scan_segment(const DevParams& P, const Sig<R>
         if (win.i == INT_MAX) { win.i = t0; win.s = (R)0; }
         sh.seg_score[sg] = win.s;
         sh.seg_t[sg] = win.i;
+    }
+}
+
+// two neighbouring segments of at most 128 positions each by one wave: their loads in ONE batch, then the two arg-maxes
+template <bool SO, typename R, typename SH>
+__device__ __forceinline__ void rp_scan_segment_pair(const DevParams& P, const Sig<R>& G, const R* w, SH& sh, int sg, int lane)
+{
+    const int t0 = (sg << P.seg_shift), tm = t0 + P.seg, t1 = min(P.T, tm + P.seg);
+    R sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = (u < 2 ? t0 : tm) + lane + 64 * (u & 1);
+        const int tend = u < 2 ? tm : t1;
+        sc[u] = (R)-1;
+        if (t < tend && (t - (u < 2 ? t0 : tm)) < P.seg) { if constexpr (SO) sc[u] = G.bc[t]; else sc[u] = score_of(G.bc[t], G.bk[t], w); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int base = h ? tm : t0, tend = h ? t1 : tm;
+        Cand<R> best; best.s = (R)-1; best.i = INT_MAX;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                    // ascending position per lane: '>' keeps the first of equals
+            const int t = base + lane + 64 * u;
+            if (t < tend && lane + 64 * u < P.seg && sc[2 * h + u] > best.s) { best.s = sc[2 * h + u]; best.i = t; }
+        }
+        Cand<R> win = rp_wave_argmax(best);
+        if (lane == 0) {
+            if (win.i == INT_MAX) { win.i = base; win.s = (R)0; }
+            sh.seg_score[sg + h] = win.s;
+            sh.seg_t[sg + h] = win.i;
+        }
     }
 }
 
@@ -133,7 +225,7 @@ __device__ __forceinline__ Cand<R> rp_block_argmax(const DevParams& P, const Sig
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int tt = tailBegin + lane + 64 * u; if (tt < hi && ts[u] > best.s) { best.s = ts[u]; best.i = tt; } }
-    return wave_argmax(best);
+    return rp_wave_argmax(best);
 }
 
 // ---- P2 by the whole workgroup (more than 64 blocks: nbBlocks='auto' on long signals): index lists in LDS --------
@@ -192,82 +284,69 @@ __device__ __forceinline__ void rp_block_select(const DevParams& P, SH& sh, int 
     __syncthreads();
 }
 
-// ---- P2 by ONE wave (at most 64 blocks): candidate j in lane j, compactions through a strip of LDS (the LDS executes
-//      a wave's operations in order: no barrier), the |c| order by a rank sort over v_readlane broadcasts ------------
+// ---- P2 by ONE wave (at most 64 blocks): candidate j stays in lane j; the filters are ballot masks, the |c| order a rank
+//      among the surviving lanes over v_readlane broadcasts (the weak-atom filter keeps the order of the sort it follows,
+//      so the final rank is the rank among its survivors).  One batch of LDS reads, one lane exchange, one write. --------
 template <typename R, typename SH>
 __device__ __forceinline__ void rp_wave_select(const DevParams& P, SH& sh, int nb, int lane)
 {
     const int T = P.T, W = P.W, F = P.F;
-    int* strip = sh.idx[0];
-    auto fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-    // lanes holding `keep` move to the front, in lane order; returns their number
-    auto compact = [&](bool keep, int& me) {
-        const unsigned long long mask = __ballot(keep);
-        if (keep) strip[__popcll(mask & ((1ull << lane) - 1ull))] = me;
-        fence();
-        const int cnt = __popcll(mask);
-        me = lane < cnt ? strip[lane] : 0;
-        fence();
-        return cnt;
-    };
-    int me = lane;
+    const bool mine = lane < nb;
+    const int t = mine ? sh.c_t[lane] : -1;
+    const R c = mine ? sh.c_c[lane] : (R)0;
+    const R eb = mine ? sh.c_eb[lane] : (R)0;
+    const int flag = mine ? sh.c_flag[lane] : RPF_INTERIOR;
+    const R e_sig = sh.e_sig;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     // :946-948 drop null coefficients (and invalid blocks)
-    bool keep = lane < nb && sh.c_t[lane] >= 0 && (P.has_thres == 0 || fabs((double)sh.c_c[lane]) > P.thres);
-    int n = compact(keep, me);
+    unsigned long long mask = __ballot(t >= 0 && (P.has_thres == 0 || fabs((double)c) > P.thres));
     bool spaced = true;
     // :951-957 interference filter vs the unfiltered predecessor; skipped when no gap qualifies
-    if (n > 1) {
-        const int t = lane < n ? sh.c_t[me] : 0;
-        const int tp = __shfl_up(t, 1);
-        const bool gap = lane >= 1 && lane < n && (t - tp >= W);
-        if (__ballot(gap) != 0ull) n = compact(lane < n && (lane == 0 || gap), me);
+    if (__popcll(mask) > 1) {
+        const unsigned long long before = mask & lt;
+        const int pl = before ? 63 - __clzll((long long)before) : lane;
+        const int tp = __shfl(t, pl);
+        const unsigned long long gaps = __ballot(((mask >> lane) & 1ull) && before != 0ull && (t - tp >= W));
+        if (gaps != 0ull) mask = gaps | (mask & (0ull - mask));                // (the first candidate always stays)
         else spaced = false;
     }
-    // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals
-    if (n > 1) {
-        const R a = lane < n ? rabs(sh.c_c[me]) : (R)0;
-        int rank = 0;
-        for (int q = 0; q < n; ++q) {
-            const R o = wave_bcast(a, q);
-            rank += (o > a || (o == a && q > lane)) ? 1 : 0;
-        }
-        if (lane < n) strip[rank] = me;
-        fence();
-        me = lane < n ? strip[lane] : 0;
-        fence();
-    }
     // :1090-1099 weak-atom filter: the window of the filter is the atom's clipped support, its energy c_eb
-    if (P.has_snr && n > 1) {
-        const R tol_energy = sh.e_sig / (R)P.snr_ratio;
+    if (P.has_snr && __popcll(mask) > 1) {
+        const R tol_energy = e_sig / (R)P.snr_ratio;
         const double thr = (double)tol_energy / (double)((int64_t)T * F);
-        keep = false;
-        if (lane < n) {
-            int s, e, es;
-            const int len = centered_span(T, W, sh.c_t[me], s, e, es);
-            const R mean = sh.c_eb[me] / (R)((int64_t)len * F);
-            keep = (double)mean >= thr;
-        }
-        n = compact(keep, me);
+        int s, e, es;
+        const int len = centered_span(T, W, t < 0 ? 0 : t, s, e, es);
+        const R mean = eb / (R)((int64_t)len * F);
+        mask = __ballot(((mask >> lane) & 1ull) && (double)mean >= thr);
     }
-    const unsigned long long edges = __ballot(lane < n && !(sh.c_flag[me] & RPF_INTERIOR));
-    if (lane < n) sh.ord[lane] = me;
-    if (lane == 0) { sh.n = n; sh.spaced = spaced ? 1 : 0; sh.nedge = __popcll(edges); }
+    // :960-962 argsort(|c|)[::-1]: descending, the later entry first among equals
+    const bool in = ((mask >> lane) & 1ull) != 0ull;
+    const R a = rabs(c);
+    int rank = 0;
+    for (unsigned long long rest = mask; rest; rest &= rest - 1ull) {        // (uniform)
+        const int q = __ffsll((long long)rest) - 1;
+        const R o = wave_bcast(a, q);
+        rank += (o > a || (o == a && q > lane)) ? 1 : 0;
+    }
+    if (in) sh.ord[rank] = lane;
+    const unsigned long long edges = __ballot(in && !(flag & RPF_INTERIOR));
+    if (lane == 0) { sh.n = __popcll(mask); sh.spaced = spaced ? 1 : 0; sh.nedge = __popcll(edges); }
 }
 
 // ---- P3 by ONE wave: bookkeeping (:1106-1114) and the fast stop rules (:1125-1142) of the atoms ord[pos, gend) in
 //      selection order, 64 atoms at a time, atom i in lane i.  The counters are prefix popcounts; the residual energy is
 //      the same chain of subtractions (:1014), carried through v_readlane; every lane tests the stop rules of its own atom
 //      and the first lane that stops cuts the group.  The lanes of the applied atoms write their slots and events. ------
-struct RpPending { int t, k, si, ev, fresh, on; double a; };
+struct RpPending { int t, k, si, ev, fresh, on, head; double a; };
 template <typename R> __device__ __forceinline__ void rp_store_pending(const DevParams& P, const Sig<R>& G, const RpPending& q, R c)
 {
     if (!q.on) return;
-    if (q.fresh) { G.slot_t[q.si] = q.t; G.slot_k[q.si] = q.k; slot_insert(G, P.hmask, q.t, q.k, q.si); }
+    if (q.fresh) { G.slot_t[q.si] = q.t; G.slot_k[q.si] = q.k; hval_store(G.hval + q.si, q.head); hval_store(G.head + q.t, q.si); }
     G.slot_a[q.si] = q.a;
     G.ev_t[q.ev] = q.t; G.ev_k[q.ev] = q.k; G.ev_c[q.ev] = c;
 }
 // (the slot / event stores of the LAST chunk are handed back: the caller issues them behind the workgroup barrier, where
-//  the other waves are already at work -- the compare-and-swap of a table insert is a memory round trip)
+//  the other waves are already at work)
 template <typename R, typename SH>
 __device__ __forceinline__ void rp_wave_prefix(const DevParams& P, SH& sh, const Sig<R>& G, int pos, int gend, int lane, RpPending& pend, R& pend_c)
 {
@@ -308,7 +387,7 @@ __device__ __forceinline__ void rp_wave_prefix(const DevParams& P, SH& sh, const
         const int take = ms ? __ffsll((long long)ms) : cnt;          // atoms of this chunk that are applied
         const unsigned long long below = take >= 64 ? ~0ull : ((1ull << take) - 1ull);
         // coefficient slot and event of the atom (:1114; :992: a new accumulator starts at 0.0)
-        pend.on = lane < take; pend.t = sh.c_t[me]; pend.k = sh.c_k[me]; pend.fresh = fresh;
+        pend.on = lane < take; pend.t = sh.c_t[me]; pend.k = sh.c_k[me]; pend.fresh = fresh; pend.head = sh.c_head[me];
         pend.si = fresh ? nslots + __popcll(m_fresh & lt) : found; pend.ev = nev + lane; pend.a = acc + (double)c; pend_c = c;
         if (!ms && base + 64 < gend) { rp_store_pending<R>(P, G, pend, pend_c); pend.on = 0; }
         nnz += __popcll(m_nnz & below); ndup += __popcll(m_dup & below); nslots += __popcll(m_fresh & below);
@@ -347,16 +426,20 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
     G.ev_t = S.ev_t + (int64_t)b * P.cap; G.ev_k = S.ev_k + (int64_t)b * P.cap; G.ev_c = S.ev_c + (int64_t)b * P.cap;
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
+    G.head = S.head + (int64_t)b * T;
     G.sel_t = nullptr; G.sel_k = nullptr; G.sel_c = nullptr;
 
     Pol::prologue(P, S, G, A, plds, b);                  // (ends with a workgroup barrier)
     const int nteams = Pol::teams(A);                    // waves that take per-atom work (each needs a strip of LDS)
     const R* wts = Pol::weights(P, S, A, plds);
 
-    // ---- segment maxima; the (t,k) -> slot table of this launch, from the slot list (always on: the probes of a
-    //      round go out side by side, one per candidate)
+    // ---- segment maxima; the (t,k) -> coefficient slot lookup of this launch (:1106-1114 looks the pair up in the dict of
+    //      coefficients): the slots of a position are chained from head[t] (most recent first) through next[] = hval[] -- the
+    //      address of the first link depends on the position only, so it is fetched beside the position's window, and a
+    //      position that was never selected costs no second round trip.  A round selects every position at most once, so
+    //      its new links are plain stores.
     for (int sg = wv; sg < P.nseg; sg += kRpWaves) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
-    for (unsigned i = tid; i <= P.hmask; i += kRpThreads) hkey_store(G.hkey + i, kSlotEmpty);
+    for (int i = tid; i < T; i += kRpThreads) hval_store(G.head + i, -1);
     if (tid == 0) {
         sh.nnz = stats[ST_NNZ]; sh.ndup = stats[ST_DUP]; sh.rounds = stats[ST_ROUNDS]; sh.iters = stats[ST_ITERS];
         sh.nev = stats[ST_EVENTS]; sh.nslots = stats[ST_SLOTS]; sh.offset = stats[ST_OFFSET];
@@ -366,13 +449,16 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
     __syncthreads();
     {
         const int ns = stats[ST_SLOTS];
-        for (int i = tid; i < ns; i += kRpThreads) slot_insert(G, P.hmask, G.slot_t[i], G.slot_k[i], i);
+        for (int i = tid; i < ns; i += kRpThreads)
+            hval_store(G.hval + i, __hip_atomic_exchange(G.head + G.slot_t[i], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     __syncthreads();
 
+    constexpr int SB = Pol::kScoreOnly ? 16 : 0;      // (diagnostic build: stamp slots of the two policies)
+    (void)SB;
     HSCMP_STAMP_BEGIN();
     for (int round = 0; P.max_rounds <= 0 || round < P.max_rounds; ++round) {
-        HSCMP_STAMP(16);                                                      // round end of the previous round
+        HSCMP_STAMP(SB + 0);                                                      // round end of the previous round
         // =========================== P1: one arg-max per block (:908-937) ===========================
         const int off = sh.offset;
         const int nb = P.nbk + (off ? 1 : 0);
@@ -383,29 +469,29 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
             const int hi = min(T, w0 + P.bs);
             Cand<R> win; win.s = (R)-1; win.i = INT_MAX;
             if (lo < hi) win = rp_block_argmax<Pol::kScoreOnly>(P, G, wts, sh, lo, hi, lane);
-            HSCMP_STAMP(25);
+            HSCMP_STAMP(SB + 9);
             bool valid = (lo < hi) && win.i != INT_MAX;                      // :940-942 range test
             if (valid && win.s == (R)0 && w0 < 0) valid = false;             // arg-max on a leading padded row
             int wk = 0, flag = 0, found = -1;
             R wc = (R)0, eb = (R)0, ea = (R)0;
             double acc = 0.0;
+            int head = -1;
             if (valid) {                                                     // wave-uniform
+                head = hval_load(G.head + win.i);                            // (in flight under the candidate's own loads)
                 Pol::candidate(P, S, G, A, plds, win.i, lane, wv, wk, wc, eb, ea, flag);
-                HSCMP_STAMP(26);
-                if (lane == 0) {
-                    unsigned pos;
-                    found = slot_find(G, P.hmask, win.i, wk, pos);
-                    if (found >= 0) acc = G.slot_a[found];
-                }
-                HSCMP_STAMP(27);
+                HSCMP_STAMP(SB + 10);
+                found = head;
+                while (found >= 0 && G.slot_k[found] != wk) found = hval_load(G.hval + found);      // (uniform)
+                if (found >= 0) acc = G.slot_a[found];
+                HSCMP_STAMP(SB + 11);
             }
             if (lane == 0) {
                 sh.c_t[j] = valid ? win.i : -1; sh.c_k[j] = wk; sh.c_c[j] = wc; sh.c_eb[j] = eb; sh.c_ea[j] = ea;
-                sh.c_found[j] = found; sh.c_acc[j] = acc; sh.c_flag[j] = flag;
+                sh.c_found[j] = found; sh.c_acc[j] = acc; sh.c_flag[j] = flag; sh.c_head[j] = head;
             }
         }
         __syncthreads();
-        HSCMP_STAMP(17);                                                      // block arg-max + candidates
+        HSCMP_STAMP(SB + 1);                                                      // block arg-max + candidates
         // =========================== P2: filters and order (:946-962, :1090-1099) ===========================
         // Up to 64 blocks: wave 0 alone, candidates in its lanes (no workgroup barrier until the atoms are known AND the
         // bookkeeping prefix of the first group is done); more blocks: the whole workgroup over index lists.
@@ -419,7 +505,7 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
             R pend_c = (R)0;
             if (wv == 0) {
                 if (pos == 0 && small) rp_wave_select<R>(P, sh, nb, lane);
-                HSCMP_STAMP(23);
+                HSCMP_STAMP(SB + 7);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 const int nn = sh.n;
@@ -448,7 +534,7 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
                         while (gend < nn && (sh.c_flag[sh.ord[gend]] & RPF_INTERIOR)) ++gend;
                     }
                     rp_wave_prefix<R>(P, sh, G, pos, gend, lane, pend, pend_c);   // (-> sh.napply, sh.gend, sh.converged / sh.stop)
-                    HSCMP_STAMP(24);
+                    HSCMP_STAMP(SB + 8);
                 }
             }
             __syncthreads();
@@ -457,14 +543,14 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
             if (sh.full) { full = true; break; }
             if (pos >= n) break;
             const int aend = sh.napply, gend = sh.gend;
-            HSCMP_STAMP(18);                                                  // filters + order + prefix
+            HSCMP_STAMP(SB + 2);                                                  // filters + order + prefix
             // ---- P4: residual subtraction (:1117, :996-1016), one wave per atom
             for (int i = pos + wv; i < aend && wv < nteams; i += nteams) {
                 const int me = sh.ord[i];
                 Pol::subtract(P, S, G, A, plds, sh.c_t[me], sh.c_k[me], sh.c_c[me], lane, wv);
             }
             __syncthreads();
-            HSCMP_STAMP(20);                                                  // subtraction
+            HSCMP_STAMP(SB + 4);                                                  // subtraction
             // ---- P5: local re-correlation of the touched rows from the final residual (:1120, :1018-1051)
             {
                 const int upa = Pol::units_per_atom(P);
@@ -477,7 +563,7 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
                 }
             }
             __syncthreads();
-            HSCMP_STAMP(21);                                                  // re-correlation
+            HSCMP_STAMP(SB + 5);                                                  // re-correlation
             // (edge history of atoms at a signal end: read next by wave 0 -- in order behind this -- or behind a later barrier)
             if ((sh.nedge > 0 || !sh.spaced) && tid == 0)
                 for (int i = pos; i < aend; ++i) {
@@ -493,28 +579,27 @@ __global__ __launch_bounds__(kRpThreads) void iterate_rp_kernel(DevParams P, Sta
         }
         // =========================== P6: segment maxima, slow stop rules (:1145-1163) ===========================
         if (n > 0 && !sh.converged) {
-            // the segments that the rows of the applied atoms lie in, one wave per (atom, segment); a segment that two atoms
-            // share is scanned twice, with the same result
-            const int mps = ((2 * W - 2) >> P.seg_shift) + 2;               // segments an atom's 2W-1 rows can touch
-            const int nu = sh.napply * mps;                                  // (the groups of a round are consecutive: ord[0, napply))
-            for (int u = wv; u < nu; u += kRpWaves) {
-                const int a = u / mps, q = u - a * mps;
+            // the segments that the rows of the applied atoms lie in, one wave per atom (its rows touch two segments as a
+            // rule: both are fetched in one batch of loads); a segment that two atoms share is scanned twice, with the same result
+            const int napplied = sh.napply;                                  // (the groups of a round are consecutive: ord[0, napply))
+            for (int a = wv; a < napplied; a += kRpWaves) {
                 const int p = sh.c_t[sh.ord[a]];
                 const int lo = max(0, p - (W - 1)), hi = min(T - 1, p + (W - 1));
-                const int sg = (lo >> P.seg_shift) + q;
-                if (sg <= (hi >> P.seg_shift)) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
+                const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
+                if (P.seg <= 128 && sg1 == sg0 + 1) rp_scan_segment_pair<Pol::kScoreOnly>(P, G, wts, sh, sg0, lane);
+                else for (int sg = sg0; sg <= sg1; ++sg) rp_scan_segment<Pol::kScoreOnly>(P, G, wts, sh, sg, lane);
             }
         }
-        HSCMP_STAMP(28);
+        HSCMP_STAMP(SB + 12);
         if (tid == 0) {
             if (n == 0) { sh.converged = 1; if (sh.stop == STOP_RUNNING) sh.stop = STOP_EMPTY; }     // :1150-1153
             sh.rounds += 1;
             sh.offset = !sh.offset;
         }
         __syncthreads();
-        HSCMP_STAMP(22);                                                      // segment maxima + round end
+        HSCMP_STAMP(SB + 6);                                                      // segment maxima + round end
 #ifdef HSCMP_DBG_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[30] += 1; g_stamps[31] += (unsigned long long)n; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[SB + 14] += 1; g_stamps[SB + 15] += (unsigned long long)n; }
 #endif
         if (sh.converged) break;
     }

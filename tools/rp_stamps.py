@@ -20,13 +20,27 @@ lib.hscmp_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
 for tm in timings:
     print('level %d: %-34s prepare %.2f init %.2f loop %.2f ms  selections %d' % (tm['level'], tm['variant'], tm['kernel_ms'][0], tm['kernel_ms'][1], tm['kernel_ms'][2], tm['selections']))
-rounds, atoms = max(v[30], 1), max(v[31], 1)
-print('round-parallel loops of workgroup 0 (all levels that ran it): %d rounds, %d atoms (%.1f per round)' % (rounds, atoms, atoms / rounds))
-names = {16: 'top of round', 17: 'P1 rest (wait for the other waves)', 18: 'P2/P3 rest (barrier)', 19: 'P3 prefix', 20: 'P4 bookkeeping stores + subtraction',
-         21: 'P5 re-correlation', 22: 'P6 rest (barriers, round end)', 23: '  wave 0: filters + order', 24: '  wave 0: prefix', 25: '  wave 0: block arg-max', 26: '  wave 0: candidate (resolve + energies)', 27: '  wave 0: slot lookup', 28: '  wave 0: segment scans', 29: '-'}
-tot = 0.0
-for i in range(16, 30):
-    if v[i] > 0:
-        print('  %-40s %9.0f cycles/round' % (names[i], v[i] / rounds))
-        tot += v[i]
-print('  %-40s %9.0f cycles/round = %.1f us at 2.4 GHz' % ('total', tot / rounds, tot / rounds / 2400.0))
+names = ['top of round', 'P1 rest (wait for the other waves)', 'P2/P3 rest (barrier, deferred slot stores)', '-', 'P4 subtraction', 'P5 re-correlation',
+         'P6 rest (barriers, round end)', '  wave 0: filters + order', '  wave 0: prefix', '  wave 0: block arg-max', '  wave 0: candidate (k, c, energies)',
+         '  wave 0: slot lookup', '  wave 0: segment scans']
+for base, what in ((16, 'matrix-core policy (level 0)'), (0, 'sparse policy (levels >= 1)')):
+    rounds, atoms = max(v[base + 14], 1), max(v[base + 15], 1)
+    print('round-parallel loop, %s, workgroup 0: %d rounds, %d atoms (%.1f per round)' % (what, rounds, atoms, atoms / rounds))
+    tot = 0.0
+    for i, nm in enumerate(names):
+        if v[base + i] > 0:
+            print('  %-44s %9.0f cycles/round' % (nm, v[base + i] / rounds))
+            tot += v[base + i]
+    print('  %-44s %9.0f cycles/round' % ('total', tot / rounds))
+cnt = (ctypes.c_ulonglong * 16)()
+lib.hscmp_debug_counters(cnt, 1)
+c = np.array(list(cnt), dtype=np.float64)
+e, r = max(c[0], 1), max(c[3], 1)
+print('sparse policy, workgroup 0 (both timed repetitions): %d energy calls, %d by the dense walk (%.2f %%), %.1f span cells on average' % (c[0], c[1], 100 * c[1] / e, c[2] / e))
+print('  %d row-range attempts: %d with an overflowed row list, %d with too many cells, %d with too many products; %.1f cells, %.1f products, longest feature list %.1f on average; %d rows by their atoms' % (
+    c[3], c[4], c[5], c[7], c[6] / r, c[8] / r, c[10] / r, c[9]))
+nm = {32: 'energies: row lists + (k, c)', 33: 'energies: cells -> list', 34: 'energies: atom cells', 35: 'energies: ranks + partial sums', 36: 'energies: dense walk (if any) + tree',
+      40: 're-correlation: gather', 41: 're-correlation: pairing', 42: 're-correlation: sort', 43: 're-correlation: chains', 44: 're-correlation: per-row best + stores'}
+rounds = max(v[14], 1)
+for i in sorted(nm):
+    print('  wave 0, %-44s %9.0f cycles/round' % (nm[i], v[i] / rounds))
