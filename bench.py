@@ -111,6 +111,8 @@ def main():
                     'nearest shape whose hierarchy is self-consistent; 16 = the literal BASELINE shape, see hsc_amd.synth.make_hierarchy)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-transfers', action='store_true', help='skip the PCIe-inclusive leg')
+    ap.add_argument('--no-secondary', action='store_true', help='config 2 only: skip the bounded runs of the hierarchical configurations (configs 4 / 5)')
+    ap.add_argument('--secondary-budget-s', type=int, default=150, help='wall-clock budget of that section')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI) or 'gloo' (rehearsal)")
     ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the CPU baseline (0 = one per usable core, at most 16: the CPU share of one GPU; the port is memory-bound and slows down beyond that)')
     ap.add_argument('--cpu-signals-per-proc', type=int, default=2, help='signals each CPU process encodes (~3-6 s each)')
@@ -226,9 +228,11 @@ def bench_cmp(args, ctx):
     del r
 
     # ---- per-kernel durations (HIP events on the engine's stream), untimed extra steps
+    #      in the regime of the timed loop: three encodes queued back to back, the events of the last one read, repeated
     kms = np.zeros(4, dtype=np.float64)
     for _ in range(max(1, args.profile_steps)):
-        step()
+        for _ in range(3):
+            step()
         stream.synchronize()
         kms += eng.last_kernel_ms().astype(np.float64)
     kms /= max(1, args.profile_steps)
@@ -357,10 +361,39 @@ def bench_cmp(args, ctx):
     }
     if check and not all(check.values()):
         out['config']['output_check']['FAILED'] = True
+    # ---- the hierarchical configurations of BASELINE.json at their own sizes, a few steps each (bounded: it must never
+    #      cost the headline line): configs[3] with 17 and with the literal 16 level-1 taps, configs[4] at its per-GPU share
+    if world == 1 and not args.no_secondary:
+        eng.close()
+        del x
+        torch.cuda.empty_cache()
+        out['secondary'] = run_secondary(args, ctx)
     if world == 1 and not args.no_cpu_baseline:
         nproc = args.cpu_procs or min(16, host_cores())
         out['cpu_baseline'] = run_cpu_baseline(cfg, nproc, args.cpu_signals_per_proc)
     return out
+
+
+def run_secondary(args, ctx):
+    import copy
+    import bench_hsc
+    sec = {}
+    t_begin = time.perf_counter()
+    for name, config, taps in (('config4_17taps', 4, 17), ('config4_16taps', 4, 16), ('config5', 5, 17)):
+        if time.perf_counter() - t_begin > args.secondary_budget_s:
+            sec[name] = {'skipped': 'time budget of the secondary section (%d s) spent' % args.secondary_budget_s}
+            continue
+        a = copy.copy(args)
+        a.config, a.level1_taps, a.batch, a.T = config, taps, 0, 65536
+        a.steps, a.warmup, a.no_cpu_baseline = 3, 1, True
+        t0 = time.perf_counter()
+        try:
+            sec[name] = bench_hsc.compact(bench_hsc.run(a, ctx))
+            sec[name]['section_wall_s'] = time.perf_counter() - t0
+        except BaseException as ex:            # (SystemExit included: reported, never fatal for the headline)
+            sec[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+        ctx['torch'].cuda.empty_cache()
+    return sec
 
 
 if __name__ == '__main__':

@@ -52,6 +52,47 @@ def build_workload(config, B, T, first, level1_taps=17, only_dictionary=False):
     return mld.withSingletonBases(), xs, kw, desc
 
 
+# ---- roofline of the level >= 1 kernels (sparse input x sparse dictionary, float64) ------------------------------------
+# What bounds them is not bandwidth but the chain of DEPENDENT memory round trips: a round of the blocked selection is a
+# fixed sequence of phases, each waiting for loads whose addresses come out of the previous one, and the signal's state
+# (its dense [T, F] float64 residual, 17-134 MB) lives beyond the L2.  The model below counts those round trips and prices
+# each at the Infinity-Cache hit latency of MI355X_MICROARCH.md (227 ns, idle chip): `frac` = model time / measured time.
+# The HBM side is reported beside it: algorithmic bytes per applied atom against 8 TB/s.
+IC_HIT_LATENCY_S = 227e-9          # MI355X_MICROARCH.md, "global_load_dword (Infinity Cache hit latency)"
+PEAK_HBM_BYTES = 8.0e12
+RP_ROUND_TRIPS = 8                 # round-parallel loop, per ROUND: block arg-max ends | (k, c) + row lists | span cells |
+                                   # subtraction: cell + list | list append | window lists | window cells | segment scan
+SEQ_ROUND_TRIPS_PER_ATOM = 6       # iterate_kernel<SparseRecorr>, per ATOM: slot probe | lists | cells | append | rows | segments
+
+
+def level_roofline(Dl, T, B, tm, nbBlocks):
+    K, W, F = Dl.shape
+    nz = float(np.count_nonzero(Dl)) / K
+    atoms = max(tm['selections'], 1)
+    loop_s = 1e-3 * max(tm['kernel_ms'][2], 1e-9)
+    rp = tm['variant'].endswith('_rp')
+    # algorithmic bytes per applied atom: row lists (count + 8 features = 36 B) of the W span rows (energies) and of the
+    # 3W-2 window rows (re-correlation), ~one listed cell per two rows (value 8 B), the atom's non-zeros (read the cell,
+    # write it: 16 B each), the 2W-1 rows of per-position best written back (coefficient 8 B + atom 4 B)
+    bytes_per_atom = (W + 3 * W - 2) * 36 + (4 * W - 2) // 2 * 8 + nz * 16 + (2 * W - 1) * 12
+    rounds = tm.get('rounds')
+    model_s = None
+    if rp and rounds:
+        model_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S            # every signal walks its own rounds, all signals side by side
+    elif not rp:
+        # (co-resident workgroups overlap: two per CU, four in the packed build -- up to 1024 signals walk side by side)
+        model_s = atoms / B * SEQ_ROUND_TRIPS_PER_ATOM * IC_HIT_LATENCY_S * max(1.0, B / 1024.0)
+    out = dict(bound='latency', kernel='iterate_rp_kernel<RpSparse>' if rp else 'iterate_kernel<SparseRecorr>',
+               atoms_per_s=atoms / loop_s, us_per_atom_per_signal=1e6 * loop_s * B / atoms,
+               dictionary_nonzeros_per_atom=nz,
+               latency_model={'round_trip_s': IC_HIT_LATENCY_S, 'dependent_round_trips': ('%d per round' % RP_ROUND_TRIPS) if rp else ('%d per atom' % SEQ_ROUND_TRIPS_PER_ATOM),
+                              'rounds_per_signal': (rounds / B) if rounds else None, 'model_ms': None if model_s is None else 1e3 * model_s,
+                              'frac': None if model_s is None else model_s / loop_s},
+               hbm={'algorithmic_bytes_per_atom': bytes_per_atom, 'achieved_gb_s': bytes_per_atom * atoms / loop_s / 1e9,
+                    'frac': bytes_per_atom * atoms / loop_s / PEAK_HBM_BYTES})
+    return out
+
+
 class _OracleLevelCoder(object):
     """cpu_baseline only: the reference's level coder restated in C (oracle/), same encode() contract."""
 
@@ -145,7 +186,7 @@ def run(args, ctx):
         _, residuals, _ = step('samples')
     torch.cuda.synchronize(dev)
     elapsed_res = (time.perf_counter() - t1) / nres
-    assert np.allclose(energies, np.sum(np.square(residuals.reshape((B, -1))), axis=1), rtol=1e-10, atol=0.0)
+    energies_match = bool(np.allclose(energies, np.sum(np.square(residuals.reshape((B, -1))), axis=1), rtol=1e-10, atol=0.0))
 
     # output check of the timed workload: the multilevel code reconstructs the signals
     snr = 10 * np.log10(np.sum(xs.astype(np.float64) ** 2, axis=1) / np.maximum(energies, 1e-300))
@@ -153,9 +194,11 @@ def run(args, ctx):
     consistent = not (config == 4 and args.level1_taps == 16)
     check = {'snr_db_min': float(snr.min()), 'snr_db_median': float(np.median(snr)), 'snr_floor_db': floor,
              'reconstructs': bool(snr.min() >= floor) if consistent else None,
+             'device_energies_match_fetched_residuals': energies_match,
              'nnz_per_level_mean': [float(np.mean([c[l].nnz for c in coefs])) for l in range(nlev)]}
-    if consistent and snr.min() < floor:
-        raise SystemExit('bench_hsc: the encode does not reconstruct its input (min SNR %.2f dB < %.1f dB)' % (snr.min(), floor))
+    # (a failed check is reported in the line, after the collectives below: a rank that left here would hang the others)
+    if (consistent and snr.min() < floor) or not energies_match:
+        check['FAILED'] = True
 
     import bench as _b
     elapsed_max, nsel_total = _b.reduce_over_ranks(ctx, args, elapsed, nsel_local)
@@ -176,10 +219,7 @@ def run(args, ctx):
             e.update(bound='mfma', init_tflops=fl_init / (tm['kernel_ms'][1] * 1e-3) / 1e12, loop_tflops=fl_loop / (tm['kernel_ms'][2] * 1e-3) / 1e12,
                      loop_frac=fl_loop / (tm['kernel_ms'][2] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
         else:
-            nz = float(np.count_nonzero(Dl)) / Dl.shape[0]
-            e.update(bound='l2-latency', note='sparse x sparse: a few dependent L2 round trips per atom; algorithmic cells per atom = '
-                     'non-zeros of the atom (%.1f on average) + the listed cells of its 3W-2 window' % nz,
-                     us_per_atom_per_signal=1e3 * tm['kernel_ms'][2] * B / max(tm['selections'], 1))
+            e.update(level_roofline(Dl, T, B, tm, nbBlocks=kw['nbBlocks']))
         levels.append(e)
     pmc = None
     try:
@@ -216,6 +256,21 @@ def run(args, ctx):
             out['cpu_baseline'] = {'error': str(ex)}
     hcmp.close()
     return out
+
+
+def compact(out):
+    """The figures of a hierarchical bench line that bench.py's default run carries in its `secondary` object."""
+    if out is None:
+        return None
+    keep = {k: out[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'value_incl_residual_transfer')}
+    keep['workload'] = out['config']['workload']
+    keep['signals_per_gpu'] = out['config']['signals_per_gpu']
+    keep['selections_per_step'] = out['config']['selections_per_step']
+    keep['kernel_ms_per_step'] = out['config']['kernel_ms_per_step']
+    keep['output_check'] = out['config']['output_check']
+    keep['residual_transfer_ms_per_step'] = out['residual_transfer']['ms_per_step']
+    keep['levels'] = out['roofline']['levels']
+    return keep
 
 
 if __name__ == '__main__':

@@ -1334,6 +1334,11 @@ template <typename R> static int run_table_open(hscmp_ctx* ctx, const void* x, i
     if ((rc = epi_buffer(ctx, kArenaTabRes, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
     if ((rc = epi_buffer(ctx, kArenaTable, (size_t)T * K * sizeof(R))) != HSCMP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaTabRes], x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    {   // the caller's buffer may be reused as soon as this returns (as hscmp_table_update promises): wait for the upload
+        hipEvent_t up = ctx->ev[0];
+        HIP_TRY(ctx, hipEventRecord(up, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(up));
+    }
     if (table_rows_are_sparse(ctx)) launch_table_rows_sparse<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 0, T, -1, (R*)ctx->d_epi[kArenaTable]);
     else launch_convolve<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 1, T, (R*)ctx->d_epi[kArenaTable]);
     HIP_TRY(ctx, hipGetLastError());

@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <utility>
 #include <stdint.h>
@@ -218,12 +219,17 @@ inline void set_segments(DevParams& P, int maxseg)
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) raises a ceiling: once a kernel has been allowed `lds` bytes on a device
 // every smaller request is covered.  The call takes the host some tens of microseconds and used to sit between two
 // queued kernels of every encode (a gap on the GPU whenever the host is not ahead of it), as did the occupancy query of
-// the persistent initial correlation: both are answered from a per-thread cache after the first time.
+// the persistent initial correlation: both are answered from a cache after the first time.
 inline hipError_t set_dyn_lds(const void* kern, size_t lds)
 {
-    static thread_local std::map<std::pair<int, const void*>, size_t> allowed;
+    // process-wide and monotone: hipFuncSetAttribute SETS the ceiling of a kernel for every thread of the process, so a
+    // thread asking for less than another thread was granted must not lower it (several host threads drive engines of
+    // their own: the LoCOMP workers of the hierarchical batch entry point)
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> allowed;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
     size_t& have = allowed[std::make_pair(dev, kern)];
     if (have >= lds && have > 0) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

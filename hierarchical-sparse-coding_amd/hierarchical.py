@@ -204,6 +204,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
 
         def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
+            # (an engine remembers the event capacity its last batch ended with: a stream of similar batches -- the bench,
+            #  a dataset -- then starts with lists that fit, instead of growing them twice per level and batch)
+            hint = getattr(eng, '_capacity_hint', None)
+            if hint is not None and hint[0] == (T, nbBlocks):
+                maxEvents = min(max(maxEvents, hint[1]), _native.max_event_capacity(T))
             params = _native.make_params(None, None, targetSnr, nbBlocks, 1e-16, eps, maxEvents, 0)
             encode(params)
             kernel_ms = [float(v) for v in eng.last_kernel_ms()]
@@ -219,6 +224,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 eng.grow_events(maxEvents)
                 eng.continue_rounds(0)
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])
+            eng._capacity_hint = ((T, nbBlocks), maxEvents)
             K = eng.K
             if device_epilogue:
                 out = None                                     # the coefficient slots stay on the device (hscmp_hierarchy_epilogue)
@@ -230,7 +236,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 else:
                     out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (T, K), 1e-16) for b in range(count)]
             tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
-                      selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()))
+                      selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()),
+                      rounds=int(stats[:, _native.STAT_ROUNDS].sum()))
             return out, tm, stats
 
         per_level = [[None] * B for _ in range(nbLevels)]
@@ -266,7 +273,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             for l in range(1, nbLevels):
                 Dl, wl = setups[l][0], setups[l][1]
                 engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
-                timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, chunks=0))
+                timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, rounds=0, chunks=0))
             if memoryBudget is None:
                 memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
             # Per signal on the device, for EVERY level >= 1 at once (each level's engine keeps its workspace while the chunk
@@ -293,7 +300,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                         if coefs is not None:
                             per_level[l][first:first + count] = coefs
                         acc = timings[l]
-                        acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['chunks'] += 1
+                        acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['rounds'] += tm['rounds']; acc['chunks'] += 1
                         acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
                 except _native.HscmpError as ex:
                     # out of device memory part-way through a chunk (the budget is an estimate): halve the chunk, run it again

@@ -24,13 +24,27 @@ def _dist():
     return dist
 
 
+FORCE_COLLECTIVES = False     # run the collectives even in a one-rank group (tests/nccl_child.py: RCCL on the box's one GPU)
+
+
 def _comm_device(device=None):
-    """Tensors of a collective live on the GPU with nccl (RCCL moves device memory), on the host with gloo."""
+    """Tensors of a collective live on the GPU with nccl (RCCL moves device memory), on the host with gloo.  Without an
+    explicit device a rank uses cuda:LOCAL_RANK -- the rule the engine follows -- and makes it current: a process that
+    never called torch.cuda.set_device would otherwise put every rank's tensors on cuda:0 (duplicate-GPU error or a hang)."""
+    import os
     import torch
     dist = _dist()
     if dist.is_initialized() and dist.get_backend() == 'nccl':
-        return device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        if device is None:
+            device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(device)
+        return device
     return torch.device('cpu')
+
+
+def _collectives_on():
+    dist = _dist()
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def broadcast_dictionary(D, weights=None, src=0, device=None):
@@ -38,7 +52,7 @@ def broadcast_dictionary(D, weights=None, src=0, device=None):
     dictionary itself as a tensor -- 64 KB at config 2, 6.3 MB for the largest level dictionary of config 4."""
     import torch
     dist = _dist()
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return D, weights
     dev = _comm_device(device)
     me = dist.get_rank()
@@ -79,6 +93,7 @@ def _engine_result_tensors(eng, device):
     import torch
     B, _, cap = eng._batch
     if device.type == 'cuda':
+        strict = _dist().is_initialized() and _dist().get_backend() == 'nccl'
         try:
             v = eng.device_view()
             ct = '<f8' if eng.dtype == np.float64 else '<f4'
@@ -90,7 +105,9 @@ def _engine_result_tensors(eng, device):
             eng.synchronize()
             return stats, en, ev_t, ev_k, ev_c
         except Exception:
-            pass                                   # (no array-interface import in this torch build: go through the host)
+            if strict:
+                raise                              # under RCCL a broken view must not hide behind host fetches
+            # (no array-interface import in this torch build: go through the host)
     t, k, c = eng.fetch_events()
     return (torch.from_numpy(eng.fetch_stats()).to(device), torch.from_numpy(eng.fetch_energies()).to(device),
             torch.from_numpy(t).to(device), torch.from_numpy(k).to(device), torch.from_numpy(c).to(device))
@@ -115,11 +132,12 @@ def gather_results(source, device=None, residuals=None):
     else:
         stats, en, ev_t, ev_k, ev_c = _engine_result_tensors(source, dev)
     world = dist.get_world_size() if dist.is_initialized() else 1
+    collect = _collectives_on()
     b = int(stats.shape[0])
     nmax = int(stats[:, 5].max().item()) if b else 0                    # HSCMP_STAT_EVENTS
     # ranks may own different numbers of signals / event counts: agree on the padded shape (two scalars)
     meta = torch.tensor([b, nmax], dtype=torch.int64, device=dev)
-    if world > 1:
+    if collect:
         metas = torch.empty((world * 2,), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(metas, meta)
         metas = metas.reshape((world, 2))
@@ -137,7 +155,7 @@ def gather_results(source, device=None, residuals=None):
         return x.contiguous()
 
     def gather(x):
-        if world == 1:
+        if not collect:
             return x.cpu().numpy()
         out = torch.empty((world * bpad,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
         dist.all_gather_into_tensor(out, x)
@@ -194,7 +212,7 @@ def encode_sharded(sequences_shard, D, encode_fn=None, gather=True, residuals=Fa
     res = encode_fn(sequences_shard, D, **kwargs)
     T = sequences_shard.shape[1]
     K = D.shape[0]
-    if not gather or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not gather or not _collectives_on():
         return dict(events=res.events, stats=np.asarray(res.stats), energies=np.asarray(res.energies),
                     coefficients=res.coefficients, residuals=np.asarray(res.residuals) if residuals else None, bytes_per_signal=0)
     b = len(res.events)

@@ -1,5 +1,6 @@
 """Child process of tests/test_parallel.py::test_gather_from_device_buffers_under_nccl: a one-rank `nccl` (= RCCL) process
-group on the one GPU of the box.  The collectives of hsc_amd.parallel then run on device tensors that are views of the
+group on the one GPU of the box, with the collectives forced on (parallel.FORCE_COLLECTIVES): `broadcast` and
+`all_gather_into_tensor` really execute in RCCL.  The collectives of hsc_amd.parallel then run on device tensors that are views of the
 engine's own buffers (no host round trip) -- the path `bench.py --gpus N` takes on a multi-GPU node."""
 import os
 import sys
@@ -16,6 +17,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%s' % sys.argv[1], world_size=1, rank=0)
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
+parallel.FORCE_COLLECTIVES = True      # a one-rank group: broadcast and all_gather_into_tensor still go through RCCL
 D = synth.make_dictionary(32, 16, seed=3)
 x = synth.make_batch(D, 2048, 0, 12, kind='planted', nb_atoms=20, seed=3)
 Db, wb = parallel.broadcast_dictionary(D, None, src=0, device=dev)
@@ -33,6 +35,9 @@ assert g['bytes_per_signal'] <= 4096
 r = eng.fetch_residual()
 g2 = parallel.gather_results(eng, device=dev, residuals=r)
 assert np.array_equal(g2['residuals'], r)
+# with no device named, the collectives run on cuda:LOCAL_RANK (the engine's rule), not on whatever device is current
+g3 = parallel.gather_results(eng)
+assert np.array_equal(g3['ev_t'], g['ev_t'])
 # the device views really are views: no copy was made of the event buffers
 st, en, et, ek, ec = parallel._engine_result_tensors(eng, dev)
 assert et.is_cuda and et.data_ptr() == eng.device_view().ev_t

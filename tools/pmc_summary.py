@@ -5,7 +5,10 @@ usage: pmc_summary.py --source '<what was profiled>' <pass-dir> [<pass-dir> ...]
 
 Per kernel (averages over its launches): every counter found, the launch duration seen by the profiler, and
   read_bytes  = 2 x FETCH_SIZE x 1024   (FETCH_SIZE is in KiB; on gfx950 it reports half of the bytes of a streaming read --
-                                         MI355X_MICROARCH.md "HBM"; re-checked on prepare_kernel, which reads its batch once)
+                                         MI355X_MICROARCH.md "HBM"; re-checked on prepare_kernel, which reads its batch once.
+                                         The x2 is calibrated for wide streaming reads: prepare, corr_init, the dense scans of the
+                                         loop prologues.  For the gathers of the level >= 1 kernels -- 4 to 32 bytes per
+                                         request -- it is an UPPER bound: the counter may already hold the full sectors.)
   write_bytes = WRITE_SIZE x 1024
   hbm_bytes_per_launch = read_bytes + write_bytes
   mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
@@ -26,6 +29,9 @@ def short(name):
     pol = re.search(r'(Mfma|Sparse|Generic|DictList|Dense)Recorr', name)
     if key == 'iterate_kernel' and pol:
         key += '[' + pol.group(1).lower() + (',x4' if re.search(r'Recorr<.*, 4>', name) else '') + ']'
+    rp = re.search(r'Rp(Mfma|Sparse)', name)
+    if key == 'iterate_rp_kernel' and rp:
+        key += '[' + rp.group(1).lower() + ']'
     return key
 
 
@@ -61,7 +67,7 @@ def main():
         out[k] = d
     # names bench.py looks up
     for k in list(out):
-        if k.startswith('iterate_kernel[mfma'):
+        if k.startswith('iterate_kernel[mfma') or k.startswith('iterate_rp_kernel[mfma'):
             out.setdefault('iterate_kernel', out[k])
             if 'hbm_bytes_per_launch' in out[k]:
                 out['level0_loop_hbm_bytes_per_launch'] = out[k]['hbm_bytes_per_launch']

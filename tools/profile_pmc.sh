@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() {  # name, counters...
     name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-transfers --profile-steps 1 "${BENCH_ARGS[@]}" > $R/gpurun_out/pmc_${tag}_$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-transfers --no-secondary --profile-steps 1 "${BENCH_ARGS[@]}" > $R/gpurun_out/pmc_${tag}_$name.log 2>&1
 }
 BENCH_ARGS=("${@}")
 run insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
