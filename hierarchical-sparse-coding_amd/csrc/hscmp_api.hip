@@ -445,14 +445,16 @@ static bool use_mfma(const hscmp_ctx* ctx, int T)
     return ctx->d_Dfrag != nullptr && T >= 3 * ctx->W - 2;
 }
 
-// Round-parallel loop (hscmp_rp.h: a 1024-thread workgroup per signal, the atoms of a blocked round side by side): for
-// batches that leave CUs idle under one 256-thread workgroup per signal.  HSCMP_RP=0/1 forces the choice (tests run
-// both; the results are bit-identical).
-static bool use_rp(const DevParams& P)
+// Round-parallel loop (hscmp_rp.h: a 1024-thread workgroup per signal, the atoms of a blocked round side by side).
+// HSCMP_RP=0/1 forces the choice (tests run both; the results are bit-identical).
+static bool use_rp(const DevParams& P, bool level_loop)
 {
     if (!P.blocked) return false;
     if (const char* e = getenv("HSCMP_RP")) return atoi(e) != 0;
-    return P.B <= mfma_device_cus();
+    // measured at the config-4 shape (profiles/r03_*): the level loops gain at every batch size (1024 signals: 28.9 ->
+    // 14.5 ms); on the matrix cores the four-signal loop catches up once every CU holds four signals (1024: 117.2 vs 117.6 ms;
+    // 512: 66.0 vs 60.7 ms)
+    return level_loop || P.B <= 3 * mfma_device_cus();
 }
 
 // the MFMA loop of a float32 batch: round-parallel when the batch is small and the round is blocked, else iterate_kernel
@@ -460,7 +462,7 @@ template <typename R> static int launch_mfma_loop(hscmp_ctx* ctx, const DevParam
 {
     ctx->rp_last = false;
     if constexpr (sizeof(R) == 4) {
-        if (use_rp(P) && rp_mfma_launch(ctx->stream, P, S, (const float*)ctx->d_Dfrag, true) == 0) {
+        if (use_rp(P, false) && rp_mfma_launch(ctx->stream, P, S, (const float*)ctx->d_Dfrag, true) == 0) {
             if (rp_mfma_launch(ctx->stream, P, S, (const float*)ctx->d_Dfrag) != 0) return -1;
             ctx->rp_last = true;
             return 0;
@@ -539,7 +541,7 @@ template <typename R> static int launch_iterate_sparse(hscmp_ctx* ctx, const Dev
     ctx->rp_last = false;
     if constexpr (sizeof(R) == 8) {
         // small batches of blocked rounds: the round-parallel loop (hscmp_rp_sparse.h), one wave per atom of the round
-        if (use_rp(P0)) {
+        if (use_rp(P0, true)) {
             State<R> S = make_state<R>(ctx);
             const SparseArgs<R> A = sparse_args<R>(ctx, P0.T, false);
             if (rp_sparse_launch<R>(ctx->stream, P0, S, A, true) == 0) {

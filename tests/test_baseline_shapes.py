@@ -158,8 +158,10 @@ def _same_results(res, res2, B):
 
 @pytest.mark.gpu
 def test_config4_real_dictionary_dims_packed_batch(monkeypatch):
-    """Exact config-4 dictionary shape (16 taps at level 1), 640 signals of 8192 samples: more than two signals per CU,
-    so the level-1 loop is the four-workgroups-per-CU build chosen by the dispatcher itself."""
+    """Exact config-4 dictionary shape (16 taps at level 1), 640 signals of 8192 samples.  The dispatcher runs both levels on
+    the round-parallel loops (csrc/hscmp_rp*.h); with HSCMP_RP=0 it falls to the loops of round 2 -- more than two signals
+    per CU: four signals per workgroup at level 0, the four-workgroups-per-CU build at level 1 -- and all of them must agree
+    on every signal, bit for bit."""
     import hsc_amd.synth as synth
     from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
     B, T, W1 = 640, 8192, 16
@@ -198,15 +200,23 @@ def test_config4_real_dictionary_dims_packed_batch(monkeypatch):
                 recon[s:e] += c * reps[l][k][s - lo:e - lo].astype(np.float64)
         assert float(np.max(np.abs((xs[b] - recon) - residuals[b]))) <= 1e-9, b
     assert all(c[0].shape == (T, 256) and c[1].shape == (T, 384) for c in coefs)
-    # determinism at batch scale, and the four-signals-per-workgroup level-0 loop (dispatched here: B > 2 x CUs) against
-    # the one-signal-per-workgroup loop on ALL signals, then three more runs of the dispatched build.  (This comparison is what exposed
-    # the reflected-sample load/store race of the fused atom body: about one signal in a thousand)
-    assert timings[0]['variant'].endswith('_x4')
+    # determinism at batch scale: the round-parallel loops (dispatched here) against the four-signals-per-workgroup level-0
+    # loop and the packed level-1 loop (HSCMP_RP=0: B > 2 x CUs) and against the one-signal-per-workgroup loop, on ALL
+    # signals, then three more runs of the dispatched build.  (This kind of comparison is what exposed the reflected-sample
+    # load/store race of the fused atom body: about one signal in a thousand)
+    assert timings[0]['variant'].endswith('_rp') and timings[1]['variant'].endswith('_rp')
+    monkeypatch.setenv('HSCMP_RP', '0')
+    coefsq, residualsq, tq = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
+    assert tq[0]['variant'].endswith('_x4') and not tq[1]['variant'].endswith('_rp')
     monkeypatch.setenv('HSCMP_MFMA_QUAD', '0')
     coefs1, residuals1, t1 = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
-    assert not t1[0]['variant'].endswith('_x4')
+    assert not t1[0]['variant'].endswith('_x4') and not t1[0]['variant'].endswith('_rp')
     monkeypatch.delenv('HSCMP_MFMA_QUAD')
-    assert np.array_equal(residuals, residuals1)
+    monkeypatch.delenv('HSCMP_RP')
+    assert np.array_equal(residuals, residuals1) and np.array_equal(residuals, residualsq)
+    for b in range(B):
+        for l in range(2):
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefsq[b][l])).nnz == 0, (b, l)
     for rep in range(3):
         coefs2, residuals2, _ = gpu.computeCoefficientsBatch(xs, mlds, **HSC_KW)
         assert np.array_equal(residuals, residuals2), rep
