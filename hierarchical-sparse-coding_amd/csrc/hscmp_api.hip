@@ -582,17 +582,30 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
 
 // Slots of the previous level an input was scattered from (level chaining): the input then already sits in the
 // residual buffer and prepare only needs the energy.
-struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; bool lists; };
+struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; bool lists; int max_slots; };
 
 template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, const void* x_dev, const ChainSource* chain = nullptr)
 {
     State<R> S = make_state<R>(ctx);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (chain)
-        hipLaunchKernelGGL((prepare_from_slots_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, chain->slot_t, chain->slot_k,
-                           chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc,
-                           chain->lists ? ctx->d_rl_cnt : nullptr, ctx->d_rl_f, kRowListCap);
-    else
+    if (chain) {
+        // long slot lists: counting sort in LDS when a word per slot fits (cell index / 256 and slot number in 32 bits)
+        int ibits = 1;
+        while ((1 << ibits) < std::max(2, chain->max_slots)) ++ibits;
+        const long long cells256 = ((long long)P.T * P.F + 255) >> 8;
+        const size_t lds = (size_t)std::max(1, chain->max_slots) * sizeof(unsigned);
+        const int sorted_min = getenv("HSCMP_SORTED_PREPARE_MIN") ? atoi(getenv("HSCMP_SORTED_PREPARE_MIN")) : 2048;
+        const bool sorted = chain->max_slots > sorted_min && lds <= (size_t)150 * 1024 && ibits < 31 && cells256 < (1ll << (32 - ibits)) &&
+                            !getenv("HSCMP_NO_SORTED_PREPARE") &&
+                            set_dyn_lds((const void*)prepare_from_slots_sorted_kernel<R>, lds) == hipSuccess;
+        if (sorted)
+            hipLaunchKernelGGL((prepare_from_slots_sorted_kernel<R>), dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, chain->slot_t, chain->slot_k,
+                               chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc, ibits);
+        else
+            hipLaunchKernelGGL((prepare_from_slots_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, chain->slot_t, chain->slot_k,
+                               chain->slot_a, chain->stats, chain->cap, chain->first, chain->has_min, chain->minc,
+                               chain->lists ? ctx->d_rl_cnt : nullptr, ctx->d_rl_f, kRowListCap);
+    } else
         hipLaunchKernelGGL((prepare_kernel<R>), dim3(P.B), dim3(kThreads), 0, ctx->stream, P, S, (const R*)x_dev);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // The matrix-core kernels come as a pair: the score-only state the initial correlation leaves is what the MFMA loop
@@ -715,8 +728,15 @@ extern "C" int hscmp_encode_batch_from_level(hscmp_ctx* ctx, hscmp_ctx* prev, in
     ctx->P = P; ctx->last = *params; ctx->B = count; ctx->T = T; ctx->cap = P.cap; ctx->maxsel = P.maxsel;
     ctx->rowflag_valid = true;                  // the sparse initial correlation skips its scan of the dense input
     ctx->rl_filled = lists;
+    // (the longest slot list of the range sizes the LDS of the energy kernel: the previous level's counters are final)
+    int max_slots = 0;
+    {
+        std::vector<int> pst((size_t)count * ST_COUNT);
+        HIP_TRY(ctx, hipMemcpy(pst.data(), prev->d_stats + (size_t)first * ST_COUNT, pst.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i) max_slots = std::max(max_slots, pst[(size_t)i * ST_COUNT + ST_SLOTS]);
+    }
     const ChainSource chain{prev->d_slot_t, prev->d_slot_k, prev->d_slot_a, prev->d_stats, prev->cap, first, has_min,
-                            has_min ? min_coefficients : 0.0, lists};
+                            has_min ? min_coefficients : 0.0, lists, max_slots};
     rc = run_encode<double>(ctx, P, ctx->d_resid, &chain);
     ctx->rowflag_valid = false; ctx->rl_filled = false;
     if (rc) return rc;
@@ -1122,7 +1142,9 @@ extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int 
     }
     int nmax = 2;
     while (nmax < last->cap) nmax <<= 1;
-    const bool need_scratch = nmax > kEpiLdsKeys;
+    int lds_keys = kEpiLdsKeys;                                  // (HSCMP_EPI_LDS_KEYS: tests force the chunked sort at small sizes)
+    if (const char* e = getenv("HSCMP_EPI_LDS_KEYS")) { const int v = atoi(e); if (v >= 64 && v <= kEpiLdsKeys && (v & (v - 1)) == 0) lds_keys = v; }
+    const bool need_scratch = true;                              // (the t-sorted keys move there while the LDS holds residual tiles)
     const size_t nres = out_residual ? (size_t)count * T * Fd * sizeof(double) : 0;
     const size_t sizes[8] = {0, (size_t)(count + 1) * sizeof(long long), (size_t)count * sizeof(int), (size_t)count * (Ktot + 1) * sizeof(int),
                              std::max<size_t>(16, (size_t)total * sizeof(int)), std::max<size_t>(16, (size_t)total * sizeof(double)),
@@ -1144,7 +1166,8 @@ extern "C" int hscmp_hierarchy_epilogue(hscmp_ctx* last, hscmp_ctx* level0, int 
         if ((rc = epi_buffer(last, kArenaEpiEnergy, (size_t)count * sizeof(double)))) return rc;
         A.out_energy = (double*)last->d_epi[kArenaEpiEnergy];
     }
-    const size_t lds = (size_t)std::min(nmax, kEpiLdsKeys) * sizeof(unsigned long long);
+    const size_t lds = std::max<size_t>((size_t)std::min(nmax, lds_keys) * sizeof(unsigned long long), getenv("HSCMP_EPI_LDS_KEYS") ? 8192 : 65536);
+    A.lds_keys = std::min(nmax, lds_keys); A.lds_bytes = (int)lds;
     const size_t xoff = (size_t)first * T * Fd * esize(level0->dtype);
     if (level0->dtype == HSCMP_F32) {
         auto kern = hier_epilogue_kernel<float>;

@@ -56,6 +56,8 @@ struct EpiArgs {
     double* out_energy;                  // [count] sum of the squared residual samples, or nullptr
     unsigned long long* scratch;         // [count][scratch_n] keys of lists that do not fit LDS
     int scratch_n;
+    int lds_keys;                        // keys that fit the dynamic LDS of the launch (a power of two)
+    int lds_bytes;                       // that LDS in bytes (the residual tiles of step 5 reuse it)
 };
 
 __device__ __forceinline__ int epi_level_of(const EpiArgs& A, int col)
@@ -82,6 +84,59 @@ __device__ __forceinline__ void epi_sort(unsigned long long* keys, int N)
     }
 }
 
+// the same sort for a list that lives in global memory and is longer than the LDS holds (`cap` keys, a power of two): every
+// run of compare-exchange steps with a distance below `cap` is carried out chunk by chunk in LDS -- load, all the steps,
+// store -- and only the steps with a larger distance pass over global memory (N = 2 cap: one such pass in all).
+__device__ __forceinline__ void epi_sort_chunked(unsigned long long* keys, int N, unsigned long long* lds, int cap)
+{
+    // stages k <= cap: every chunk is sorted on its own, in the direction its position in the final network asks for
+    for (int c0 = 0; c0 < N; c0 += cap) {
+        for (int p = threadIdx.x; p < cap; p += kEpiThreads) lds[p] = keys[c0 + p];
+        __syncthreads();
+        for (int k = 2; k <= cap; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = threadIdx.x; p < (cap >> 1); p += kEpiThreads) {
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int q = i | j;
+                    const unsigned long long a = lds[i], b = lds[q];
+                    const bool asc = ((c0 + i) & k) == 0;
+                    if ((a > b) == asc) { lds[i] = b; lds[q] = a; }
+                }
+                __syncthreads();
+            }
+        for (int p = threadIdx.x; p < cap; p += kEpiThreads) keys[c0 + p] = lds[p];
+        __syncthreads();
+    }
+    for (int k = cap << 1; k <= N; k <<= 1) {
+        for (int j = k >> 1; j >= cap; j >>= 1) {                // distances that cross chunks: over global memory
+            for (int p = threadIdx.x; p < (N >> 1); p += kEpiThreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int q = i | j;
+                const unsigned long long a = keys[i], b = keys[q];
+                const bool asc = (i & k) == 0;
+                if ((a > b) == asc) { keys[i] = b; keys[q] = a; }
+            }
+            __syncthreads();
+        }
+        for (int c0 = 0; c0 < N; c0 += cap) {                    // the rest of the merge inside each chunk
+            for (int p = threadIdx.x; p < cap; p += kEpiThreads) lds[p] = keys[c0 + p];
+            __syncthreads();
+            for (int j = cap >> 1; j > 0; j >>= 1) {
+                for (int p = threadIdx.x; p < (cap >> 1); p += kEpiThreads) {
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int q = i | j;
+                    const unsigned long long a = lds[i], b = lds[q];
+                    const bool asc = ((c0 + i) & k) == 0;
+                    if ((a > b) == asc) { lds[i] = b; lds[q] = a; }
+                }
+                __syncthreads();
+            }
+            for (int p = threadIdx.x; p < cap; p += kEpiThreads) keys[c0 + p] = lds[p];
+            __syncthreads();
+        }
+    }
+}
+
 template <typename XR>
 __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, const XR* __restrict__ x)
 {
@@ -92,7 +147,10 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
     const int nslots = A.stats[(int64_t)b * ST_COUNT + ST_SLOTS];
     int N = 2;
     while (N < nslots) N <<= 1;
-    unsigned long long* keys = N <= kEpiLdsKeys ? reinterpret_cast<unsigned long long*>(smem) : A.scratch + (int64_t)b * A.scratch_n;
+    // (A.lds_keys: how many keys the LDS of this launch holds -- kEpiLdsKeys, less under HSCMP_EPI_LDS_KEYS in the tests)
+    unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(smem);
+    const bool in_lds = N <= A.lds_keys;
+    unsigned long long* keys = in_lds ? lds_keys : A.scratch + (int64_t)b * A.scratch_n;
     const int* st = A.slot_t + (int64_t)b * A.cap;
     const int* sk = A.slot_k + (int64_t)b * A.cap;
     const double* sa = A.slot_a + (int64_t)b * A.cap;
@@ -116,7 +174,7 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
     const int nk = s_kept;
-    epi_sort(keys, N);
+    if (in_lds) epi_sort(keys, N); else epi_sort_chunked(keys, N, lds_keys, A.lds_keys);
 
     // ---- 2. CSC out: indices, data, column pointers over the last level's columns
     int* colptr = A.out_colptr + (int64_t)b * (A.Ktot + 1);
@@ -145,7 +203,7 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
         keys[j] = key;
     }
     __syncthreads();
-    epi_sort(keys, N);
+    if (in_lds) epi_sort(keys, N); else epi_sort_chunked(keys, N, lds_keys, A.lds_keys);
 
     // ---- 4. event records in the reference's order: time, then level, then index (dataset.py:798-811)
     if (A.out_events) {
@@ -167,14 +225,34 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
         double* rb = A.out_residual ? A.out_residual + (int64_t)b * nel : nullptr;
         const double* data = A.out_data + off;
         double esum = 0.0;                                   // this thread's samples, in index order
-        for (int64_t e = tid; e < nel; e += kEpiThreads) {
+        // One-dimensional signals: tile by tile in LDS.  The entries whose patterns reach a tile of TS samples are a range of
+        // the t-sorted keys; sorted by CSC rank they fall into one run per level (a level owns a range of columns).  Every
+        // wave owns a strip of the tile and walks the run of the level IN THAT ORDER, adding the taps that land on its strip
+        // (the order in which the reference's sequential overlap-add reaches each sample); then recon += level, level after
+        // level, and the thread that owns sample s (s mod 1024, as in the per-sample form below: the energy sum keeps its
+        // order) takes x - recon.  A tile with more entries than the LDS list holds takes the per-sample form.
+        int TS = 0;
+        if (A.Fd == 1 && nk > 0) {
+            TS = 4096;
+            while (TS > 256 && (size_t)TS * 32 > (size_t)A.lds_bytes) TS >>= 1;       // sig + recon + (key, value) per entry
+            if ((size_t)TS * 32 > (size_t)A.lds_bytes || A.max_back + A.max_fwd + TS >= (1 << 13)) TS = 0;
+        }
+        const unsigned long long* gk = keys;
+        if (TS > 0 && in_lds) {
+            // the keys move to the global scratch row: the LDS is about to hold the tiles
+            unsigned long long* row = A.scratch + (int64_t)b * A.scratch_n;
+            for (int i = tid; i < nk; i += kEpiThreads) row[i] = keys[i];
+            gk = row;
+            __syncthreads();
+        }
+        auto per_sample = [&](int64_t e) {
             const int s = (int)(e / A.Fd), fd = (int)(e - (int64_t)s * A.Fd);
             // first entry with t >= s - max_back (binary search over the t-sorted keys)
             const long long tlo = (long long)s - A.max_back;
             int lo = 0, hi = nk;
             if (tlo > 0) {
                 const unsigned long long bound = (unsigned long long)tlo << (kEpiColBits + kEpiIdxBits);
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < bound) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (gk[mid] < bound) lo = mid + 1; else hi = mid; }
             }
             const int i0 = lo;
             const long long thi = (long long)s + A.max_fwd;
@@ -187,7 +265,7 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
                 for (;;) {
                     int best = INT_MAX, bt = 0, bcol = 0;
                     for (int i = i0; i < nk; ++i) {
-                        const unsigned long long k3 = keys[i];
+                        const unsigned long long k3 = gk[i];
                         const long long t = (long long)(k3 >> (kEpiColBits + kEpiIdxBits));
                         if (t > thi) break;
                         const int col = (int)((k3 >> kEpiIdxBits) & ((1u << kEpiColBits) - 1u));
@@ -210,6 +288,99 @@ __global__ __launch_bounds__(kEpiThreads) void hier_epilogue_kernel(EpiArgs A, c
             const double rv = (double)xb[e] - recon;
             if (rb) rb[e] = rv;
             esum = esum + rv * rv;
+        };
+        if (TS == 0) {
+            for (int64_t e = tid; e < nel; e += kEpiThreads) per_sample(e);
+        } else {
+            double* sig = reinterpret_cast<double*>(smem);                        // [TS]
+            double* recon = sig + TS;                                             // [TS]
+            unsigned long long* ekey = reinterpret_cast<unsigned long long*>(recon + TS);   // [TS]  CSC rank | t - tbase | column
+            double* eval = reinterpret_cast<double*>(ekey + TS);                  // [TS]
+            __shared__ int s_range[2 + kEpiMaxLevels + 1];
+            const int lane = tid & 63, wv = tid >> 6, strip = TS / (kEpiThreads / 64);
+            for (int t0 = 0; t0 < A.T; t0 += TS) {
+                const int tn = min(TS, A.T - t0);
+                const long long tbase = (long long)t0 - A.max_back;
+                if (tid < 2) {
+                    // entries with t in [t0 - max_back, t0 + tn - 1 + max_fwd]
+                    const long long tq = tid == 0 ? tbase : (long long)t0 + tn + A.max_fwd;
+                    int lo = 0, hi = nk;
+                    if (tq > 0) {
+                        const unsigned long long bound = (unsigned long long)tq << (kEpiColBits + kEpiIdxBits);
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (gk[mid] < bound) lo = mid + 1; else hi = mid; }
+                    }
+                    s_range[tid] = lo;
+                }
+                __syncthreads();
+                const int i0 = s_range[0], ne = s_range[1] - s_range[0];
+                if (ne > TS) {                                                    // (uniform) too dense for the list: per sample
+                    for (int s = t0 + tid; s < t0 + tn; s += kEpiThreads) per_sample(s);
+                    __syncthreads();
+                    continue;
+                }
+                int NE = 2;
+                while (NE < ne) NE <<= 1;
+                for (int i = tid; i < NE; i += kEpiThreads) {
+                    unsigned long long key = ~0ull;
+                    if (i < ne) {
+                        const unsigned long long k3 = gk[i0 + i];
+                        const long long t = (long long)(k3 >> (kEpiColBits + kEpiIdxBits));
+                        const unsigned long long col = (k3 >> kEpiIdxBits) & ((1u << kEpiColBits) - 1u), j = k3 & ((1u << kEpiIdxBits) - 1u);
+                        key = (j << (13 + kEpiColBits)) | ((unsigned long long)(t - tbase) << kEpiColBits) | col;
+                    }
+                    ekey[i] = key;
+                }
+                for (int s = tid; s < TS; s += kEpiThreads) recon[s] = 0.0;
+                __syncthreads();
+                epi_sort(ekey, NE);
+                for (int i = tid; i < ne; i += kEpiThreads) eval[i] = data[(int)(ekey[i] >> (13 + kEpiColBits))];
+                // run of every level in the rank-sorted list (ranks ascend with the column)
+                if (tid <= A.nlevels) {
+                    int pos = ne;
+                    if (tid < A.nlevels) {
+                        const int c0 = A.lv[tid].col0;
+                        int lo = 0, hi = ne;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(ekey[mid] & ((1u << kEpiColBits) - 1u)) < c0) lo = mid + 1; else hi = mid; }
+                        pos = lo;
+                    }
+                    s_range[2 + tid] = pos;
+                }
+                __syncthreads();
+                for (int l = 0; l < A.nlevels; ++l) {
+                    const EpiLevel& L = A.lv[l];
+                    if (L.col1 <= L.col0) continue;
+                    for (int s = tid; s < TS; s += kEpiThreads) sig[s] = 0.0;
+                    __syncthreads();
+                    // this level's run: from its first column to the first entry of a column beyond its last
+                    const int r0 = s_range[2 + l];
+                    const int sub0 = t0 + wv * strip, sub1 = min(t0 + tn, sub0 + strip);
+                    for (int i = r0; i < ne; ++i) {                               // (uniform per wave)
+                        const unsigned long long key = ekey[i];
+                        const int col = (int)(key & ((1u << kEpiColBits) - 1u));
+                        if (col >= L.col1) break;
+                        const int t = (int)(tbase + (long long)((key >> kEpiColBits) & 0x1fffu));
+                        const int first = t - L.lead;
+                        const int lo = max(first, sub0), hi = min(first + L.scale, sub1);
+                        if (lo >= hi) continue;
+                        const double c = eval[i];
+                        for (int s = lo + lane; s < hi; s += 64) {
+                            const int64_t ri = (int64_t)col * L.scale + (s - first);
+                            const double rv = L.rep_f32 ? (double)reinterpret_cast<const float*>(L.rep)[ri] : reinterpret_cast<const double*>(L.rep)[ri];
+                            const double prod = c * rv;                           // c * D[k] rounded, then += (utils.py:120,129)
+                            sig[s - t0] = sig[s - t0] + prod;
+                        }
+                    }
+                    __syncthreads();
+                    for (int s = tid; s < tn; s += kEpiThreads) recon[s] = recon[s] + sig[s];      // reconstruction += reconstructSignal(level)
+                    __syncthreads();
+                }
+                for (int s = t0 + tid; s < t0 + tn; s += kEpiThreads) {
+                    const double rv = (double)xb[s] - recon[s - t0];
+                    if (rb) rb[s] = rv;
+                    esum = esum + rv * rv;
+                }
+                __syncthreads();
+            }
         }
         if (A.out_energy) {
             // fixed summation order: per thread over its strided samples, xor tree inside the wave, the 16 wave sums in order

@@ -152,6 +152,116 @@ __global__ __launch_bounds__(kThreads) void prepare_from_slots_kernel(DevParams 
     }
 }
 
+// The same energy by a counting sort of the slots: partial sum q owns the cells with index = q mod 256 and adds them in
+// ascending index.  One word per kept slot -- (cell index / 256) above the slot number, `ibits` bits -- is dealt to the
+// bucket of its partial sum in LDS (histogram, prefix, scatter), thread q sorts its bucket (a few dozen words) and walks it.
+// No pass over rows, no scan of the whole list per thread: 17 k slots per signal (BASELINE config 5) take tens of
+// microseconds where the row-list walk of prepare_from_slots_kernel takes 9 ms.
+//   grid = count, block = kThreads, dynamic LDS = 4 * max slots;   requires cell index / 256 < 2^(32 - ibits), slots < 2^ibits
+template <typename R>
+__global__ __launch_bounds__(kThreads) void prepare_from_slots_sorted_kernel(DevParams P, State<R> S, const int* __restrict__ slot_t,
+                                                                             const int* __restrict__ slot_k, const double* __restrict__ slot_a,
+                                                                             const int* __restrict__ pstats, int pcap, int first, int has_min,
+                                                                             double minc, int ibits)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* words = reinterpret_cast<unsigned*>(smem);
+    __shared__ R red[2 * kWaves];
+    __shared__ int cnt[kThreads], start[kThreads + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, src = first + b;
+    const int n = pstats[(int64_t)src * ST_COUNT + ST_SLOTS];
+    const int* st = slot_t + (int64_t)src * pcap;
+    const int* sk = slot_k + (int64_t)src * pcap;
+    const double* sa = slot_a + (int64_t)src * pcap;
+    auto kept = [&](double a) { return !(a == 0.0 || (has_min && !(fabs(a) >= minc))); };
+    cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kThreads)
+        if (kept(sa[i])) atomicAdd(&cnt[(int)(((long long)st[i] * P.F + sk[i]) & (kThreads - 1))], 1);
+    __syncthreads();
+    if (tid < 64) {                                      // exclusive prefix over the 256 buckets by one wave
+        int c4[4], local = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c4[u] = cnt[4 * tid + u]; local += c4[u]; }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+        int run = incl - local;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { start[4 * tid + u] = run; run += c4[u]; }
+        if (tid == 63) start[kThreads] = incl;
+    }
+    __syncthreads();
+    cnt[tid] = 0;                                        // cursors
+    __syncthreads();
+    for (int i = tid; i < n; i += kThreads)
+        if (kept(sa[i])) {
+            const long long c = (long long)st[i] * P.F + sk[i];
+            const int q = (int)(c & (kThreads - 1));
+            words[start[q] + atomicAdd(&cnt[q], 1)] = ((unsigned)(c >> 8) << ibits) | (unsigned)i;
+        }
+    __syncthreads();
+    // every bucket in ascending cell index (the words are distinct).  The buckets are as uneven as the atoms of the level
+    // below are popular -- cell index mod 256 is the atom number when that level has 128 or 256 atoms -- so a bucket is
+    // sorted by a WAVE: every lane counts the smaller words for its entries (LDS broadcast reads), then all write.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int q = wv; q < kThreads; q += kWaves) {
+            const int s0 = start[q], m = start[q + 1] - s0;
+            if (m < 2) continue;                                             // (uniform)
+            if (m > 16 * 64) {                                               // beyond the registers of a wave: one lane, insertion sort
+                if (lane == 0)
+                    for (int i = s0 + 1; i < s0 + m; ++i) {
+                        const unsigned w = words[i];
+                        int j = i;
+                        while (j > s0 && words[j - 1] > w) { words[j] = words[j - 1]; --j; }
+                        words[j] = w;
+                    }
+                continue;
+            }
+            unsigned mine[16];
+            int rank[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { mine[u] = lane + 64 * u < m ? words[s0 + lane + 64 * u] : 0xffffffffu; rank[u] = 0; }
+            for (int j0 = 0; j0 < m; j0 += 4) {
+                unsigned o[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) o[v] = j0 + v < m ? words[s0 + j0 + v] : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (64 * u < m) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) rank[u] += o[v] < mine[u] ? 1 : 0;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (lane + 64 * u < m) words[s0 + rank[u]] = mine[u];
+        }
+    }
+    __syncthreads();
+    const int b0 = start[tid], b1 = start[tid + 1];
+    R p = (R)0, q2 = (R)0;
+    const unsigned imask = (1u << ibits) - 1u;
+    constexpr int kU = 8;                                // loads of a batch issued together
+    for (int i0 = b0; i0 < b1; i0 += kU) {
+        double a[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) a[u] = i0 + u < b1 ? sa[words[i0 + u] & imask] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (i0 + u < b1) { const R v = (R)a[u]; const R sq = v * v; p = p + sq; }
+    }
+    pinned_tree2(p, q2, red);
+    if (tid == 0) {
+        S.energy[2 * b + 0] = p;
+        S.energy[2 * b + 1] = p;
+        int* stt = S.stats + (int64_t)b * ST_COUNT;
+        for (int i = 0; i < ST_COUNT; ++i) stt[i] = 0;
+        for (int i = 0; i < kEdgeWords; ++i) S.edge[kEdgeWords * b + i] = 0ull;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic initial correlation: one thread per output position, all atoms, pinned fma chain
 //   grid = (ceil(Tout/kThreads), B), block = kThreads

@@ -173,3 +173,35 @@ def test_level_shaped_round_parallel_vs_sequential_vs_oracle(case, monkeypatch):
         assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c']), case
         assert np.array_equal(rp.residuals[1], r), case
         assert rp.stop_reasons()[1] == info['stop']
+
+
+def test_rounds_of_more_than_64_blocks(monkeypatch):
+    """nbBlocks='auto' on a long signal: 256 blocks per round -- the filters run over index lists by the whole workgroup
+    (rp_block_select), the bookkeeping prefix in chunks of 64 atoms."""
+    import hsc_amd.synth as synth
+    from oracle import hsc_oracle as orc
+    D = synth.make_dictionary(32, 16, seed=70)
+    T = 16384
+    xs = np.stack([synth.make_signal(D, T, i, kind='planted', nb_atoms=T // 40, noise=0.03, seed=70) for i in range(3)])
+    for kw in (dict(nbBlocks='auto', nbNonzeroCoefs=700), dict(nbBlocks='auto', toleranceSnr=18.0), dict(nbBlocks=200, nbNonzeroCoefs=150)):
+        rp = _encode(xs, D, '1', monkeypatch, **kw)
+        assert rp.variant.endswith('_rp'), rp.variant
+        seq = _encode(xs, D, '0', monkeypatch, **kw)
+        _same(rp, seq, 3)
+        coef, r, info = orc.cmp_encode(xs[2], D, **kw)
+        t, k, c = rp.events[2]
+        assert np.array_equal(t, info['t']) and np.array_equal(k, info['k']) and np.array_equal(c, info['c'])
+        assert rp.stop_reasons()[2] == info['stop']
+
+
+def test_more_signals_than_compute_units(monkeypatch):
+    """A batch larger than the chip: the workgroups of the round-parallel loop run in several waves of residency."""
+    import hsc_amd.synth as synth
+    D = synth.make_dictionary(48, 16, seed=71)
+    B, T = 600, 2048
+    xs = synth.make_batch(D, T, 0, B, kind='planted', nb_atoms=40, noise=0.02, seed=71)
+    kw = dict(nbBlocks=6, toleranceSnr=25.0)
+    rp = _encode(xs, D, '1', monkeypatch, **kw)
+    assert rp.variant.endswith('_rp')
+    seq = _encode(xs, D, '0', monkeypatch, **kw)
+    _same(rp, seq, B)

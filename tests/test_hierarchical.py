@@ -236,6 +236,16 @@ def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed,
             assert (scipy.sparse.csc_matrix(got_c[l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (seed, b, l, 'per-signal')
             assert (scipy.sparse.csc_matrix(coefs_b[b][l]) != scipy.sparse.csc_matrix(exp_c[l])).nnz == 0, (seed, b, l, 'batch')
         assert np.array_equal(got_r, exp_r) and np.array_equal(residuals_b[b], exp_r)
+    # the signal energy of a chained level through the counting sort of its input slots (csrc: prepare_from_slots_sorted_kernel,
+    # dispatched for long slot lists only) and without it: the same stop decisions, the same everything
+    for key, val in (('HSCMP_SORTED_PREPARE_MIN', '0'), ('HSCMP_NO_SORTED_PREPARE', '1')):
+        monkeypatch.setenv(key, val)
+        coefs_s, residuals_s, _ = gpu.computeCoefficientsBatch(xs, mlds, **kw)
+        monkeypatch.delenv(key)
+        assert np.array_equal(residuals_s, residuals_b), (seed, key)
+        for b in range(xs.shape[0]):
+            for l in range(nlev):
+                assert (scipy.sparse.csc_matrix(coefs_s[b][l]) != scipy.sparse.csc_matrix(coefs_b[b][l])).nnz == 0, (seed, b, l, key)
     gpu.close()
 
 
@@ -261,11 +271,16 @@ def test_hierarchical_batch_with_locomp_runs_signal_by_signal():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('lds_keys', [None, '64'])
 @pytest.mark.parametrize('distributed', [True, False])
-def test_device_epilogue_equals_host_epilogue(distributed):
+def test_device_epilogue_equals_host_epilogue(distributed, lds_keys, monkeypatch):
     """hscmp_hierarchy_epilogue (redistribution, CSC, events, residual on the device) against the host epilogue
     (hscmp_host_slots_to_csc + scipy column slicing + hscmp_host_overlap_add): coefficient matrices, event records and
-    the float64 residual bit for bit; 3 levels, several chunks."""
+    the float64 residual bit for bit; 3 levels, several chunks.  HSCMP_EPI_LDS_KEYS=64: the slot lists do not fit the
+    key buffer in LDS -- the sorts run chunk by chunk through global memory (as for more than 16384 slots per signal), and the
+    residual tiles are small enough that some are denser than their entry list (the per-sample form)."""
+    if lds_keys is not None:
+        monkeypatch.setenv('HSCMP_EPI_LDS_KEYS', lds_keys)
     from hsc_amd.dataset import convertSparseMatricesToEvents
     from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
     z = _golden()
