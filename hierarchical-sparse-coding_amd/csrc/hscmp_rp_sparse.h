@@ -224,7 +224,6 @@ template <typename R> struct RpSparse {
             if (s + 64 * ps >= e) break;                      // (uniform: a span of at most 64 rows has no second pass)
             const int g = s + lane + 64 * ps;
             const bool row_on = g < e;
-            if (row_on && n_[ps] > 8) bad = true;
             const int fs[8] = {a_[ps].x, a_[ps].y, a_[ps].z, a_[ps].w, b_[ps].x, b_[ps].y, b_[ps].z, b_[ps].w};
             const bool cells_on = row_on && n_[ps] > 0 && n_[ps] <= 8;
             R vs[8];
@@ -241,6 +240,26 @@ template <typename R> struct RpSparse {
                     if (j < nzcap) { L.ckey[j] = (g - s) * F + fs[u]; L.cbefore[j] = vs[u]; L.cafter[j] = vs[u]; }
                     ++j;
                 }
+            // rows whose list has overflowed (cancelled cells stay listed: a busy row fills up) are read densely -- those
+            // rows only, the lanes over the features
+            for (unsigned long long ovf = __ballot(row_on && n_[ps] > 8); ovf; ovf &= ovf - 1ull) {          // (uniform)
+                const int go = s + 64 * ps + (__ffsll((long long)ovf) - 1);
+                for (int f0 = 0; f0 < F; f0 += 256) {
+                    R v4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int f = f0 + lane + 64 * u; v4[u] = f < F ? G.r[(int64_t)go * F + f] : (R)0; }
+                    int cntz = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cntz += (v4[u] != (R)0) ? 1 : 0;
+                    int jo = cntz > 0 ? atomicAdd(&L.ctl[0], cntz) : 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (v4[u] != (R)0) {
+                            if (jo < nzcap) { L.ckey[jo] = (go - s) * F + f0 + lane + 64 * u; L.cbefore[jo] = v4[u]; L.cafter[jo] = v4[u]; }
+                            ++jo;
+                        }
+                }
+            }
         }
         fence();
         for (int g0 = s + 64 * kPass; g0 < e; g0 += 64) bad = true;           // (W > 128: not on this path)
@@ -282,37 +301,40 @@ template <typename R> struct RpSparse {
         const int n = L.ctl[0];
         if (n > nzcap) bad = true;
         HSCMP_RP_SSTAMP(34);
-        // rank of every cell among the cells of its partial sum (cell index mod 256), ascending cell index
-        if (!bad) {
-            for (int j = lane; j < n; j += 64) {
-                const int key = L.ckey[j], q = key & 255;
-                int rank = 0;
-                for (int j2 = 0; j2 < n; j2 += 4) {
-                    const int k0 = L.ckey[j2], k1 = j2 + 1 < n ? L.ckey[j2 + 1] : -1, k2 = j2 + 2 < n ? L.ckey[j2 + 2] : -1, k3 = j2 + 3 < n ? L.ckey[j2 + 3] : -1;
-                    rank += ((k0 & 255) == q && k0 < key) ? 1 : 0;
-                    rank += (k1 >= 0 && (k1 & 255) == q && k1 < key) ? 1 : 0;
-                    rank += (k2 >= 0 && (k2 & 255) == q && k2 < key) ? 1 : 0;
-                    rank += (k3 >= 0 && (k3 & 255) == q && k3 < key) ? 1 : 0;
-                }
-                atomicAdd(&L.members[q], 1);
-                if (rank < 4) L.cell01[4 * q + rank] = (unsigned short)j;
+        // The pinned order: partial sum q adds the cells with index = q mod 256 in ascending index.  Up to 64 cells (the
+        // rule): every lane holds one; the cells are sorted by (partial sum, index) with a rank count over v_readlane
+        // broadcasts, their squares go to LDS in that order and the lane of a partial sum walks its run, however long.
+        // More cells than lanes: the dense walk below.
+        if (n > 64) bad = true;
+        R pb[4] = {(R)0, (R)0, (R)0, (R)0}, pa[4] = {(R)0, (R)0, (R)0, (R)0};
+        if (__ballot(bad) == 0ull) {
+            const int i = lane < n ? L.ckey[lane] : -1;
+            const R vb = lane < n ? L.cbefore[lane] : (R)0, va = lane < n ? L.cafter[lane] : (R)0;
+            fence();                                           // (the squares below go over the cell list)
+            R* sb = L.cbefore; R* sa = L.cafter;               // [64] squares before / after, sorted
+            unsigned short* first = L.cell01;                  // [256] start of the run of a partial sum
+            const int skey = i >= 0 ? ((i & 255) << 22) | (i >> 8) : (0x40000000 | lane);
+            int pos = 0, before_same = 0;
+            for (int q = 0; q < n; ++q) {
+                const int kq = __builtin_amdgcn_readlane(skey, q);
+                pos += kq < skey ? 1 : 0;
+                before_same += (kq < skey && (kq >> 22) == (skey >> 22)) ? 1 : 0;
             }
-        }
-        fence();
-        R pb[4], pa[4];
+            if (i >= 0) {
+                sb[pos] = vb * vb; sa[pos] = va * va;
+                atomicAdd(&L.members[i & 255], 1);
+                if (before_same == 0) first[i & 255] = (unsigned short)pos;
+            }
+            fence();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = lane + 64 * u;
-            const int m = L.members[q];
-            if (m > 4) bad = true;
-            R b = (R)0, a = (R)0;
-            for (int r = 0; r < min(m, 4); ++r) {
-                const int j = L.cell01[4 * q + r];
-                const R vb = L.cbefore[j], va = L.cafter[j];
-                const R sb = vb * vb, sa = va * va;
-                b = b + sb; a = a + sa;
+            for (int u = 0; u < 4; ++u) {
+                const int q = lane + 64 * u;
+                const int m = L.members[q];
+                const int f0 = m > 0 ? first[q] : 0;
+                R bsum = (R)0, asum = (R)0;
+                for (int r = 0; r < m; ++r) { bsum = bsum + sb[f0 + r]; asum = asum + sa[f0 + r]; }
+                pb[u] = bsum; pa[u] = asum;
             }
-            pb[u] = b; pa[u] = a;
         }
         HSCMP_RP_SSTAMP(35);
         HSCMP_RP_TALLY(0, 1); HSCMP_RP_TALLY(1, __ballot(bad) != 0ull); HSCMP_RP_TALLY(2, L.ctl[0]);
@@ -423,7 +445,26 @@ template <typename R> struct RpSparse {
             for (int ps = 0; ps < 2; ++ps) {
                 const int j = j0 + 64 * ps + lane;
                 const bool on = j < nwin;
-                if (on && n_[ps] > 8) atomicAdd(&L.ctl[1], 1);
+                // a row whose list has overflowed is read densely (that row only), the lanes over the features
+                for (unsigned long long ovf = __ballot(on && n_[ps] > 8); ovf; ovf &= ovf - 1ull) {              // (uniform)
+                    const int src = __ffsll((long long)ovf) - 1;
+                    const int jo = j0 + 64 * ps + src, go = __builtin_amdgcn_readlane(gg_[ps], src);
+                    for (int f0 = 0; f0 < F; f0 += 256) {
+                        R v4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int f = f0 + lane + 64 * u; v4[u] = f < F ? G.r[(int64_t)go * F + f] : (R)0; }
+                        int cntz = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cntz += (v4[u] != (R)0) ? 1 : 0;
+                        int oo = cntz > 0 ? atomicAdd(&L.ctl[0], cntz) : 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (v4[u] != (R)0) {
+                                if (oo < caps.nz) { L.val[oo] = v4[u]; L.key[oo] = ((f0 + lane + 64 * u) << 16) | jo; }
+                                ++oo;
+                            }
+                    }
+                }
                 const bool cells_on = on && n_[ps] > 0 && n_[ps] <= 8;
                 const int fs[8] = {a_[ps].x, a_[ps].y, a_[ps].z, a_[ps].w, b_[ps].x, b_[ps].y, b_[ps].z, b_[ps].w};
                 R vs[8];
