@@ -78,7 +78,8 @@ def level_roofline(Dl, T, B, tm, nbBlocks):
     rounds = tm.get('rounds')
     model_s = None
     if rp and rounds:
-        model_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S            # every signal walks its own rounds, all signals side by side
+        # every signal walks its own rounds; one workgroup per CU: up to 256 signals side by side, the rest queue behind them
+        model_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S * max(1.0, np.ceil(B / 256.0))
     elif not rp:
         # (co-resident workgroups overlap: two per CU, four in the packed build -- up to 1024 signals walk side by side)
         model_s = atoms / B * SEQ_ROUND_TRIPS_PER_ATOM * IC_HIT_LATENCY_S * max(1.0, B / 1024.0)

@@ -251,9 +251,21 @@ class Engine(object):
     def synchronize(self):
         self._check(self._lib.hscmp_synchronize(self._h), 'hscmp_synchronize')
 
-    def set_dictionary(self, D, weights=None):
-        """D [K,W] or [K,W,F] float32/float64 (C order); weights [K] or None."""
+    def set_dictionary(self, D, weights=None, dtype=None):
+        """D [K,W] or [K,W,F] float32/float64 (C order); weights [K] or None.  dtype: convert D (and the weights) to this
+        type for the upload -- the identity check runs on the caller's own array first, so an unchanged dictionary costs
+        one checksum of the source and no conversion (a level dictionary of BASELINE config 5 is 70 MB as float64)."""
         assert D.ndim in (2, 3)
+        if dtype is not None and D.dtype != np.dtype(dtype):
+            src = np.ascontiguousarray(D)
+            skey = (_dictionary_key(src.reshape((src.shape[0], src.shape[1], -1)), None if weights is None else np.ascontiguousarray(weights)), np.dtype(dtype).str)
+            if skey == getattr(self, '_src_key', None) and getattr(self, '_dict_key', None) is not None:
+                return
+            self._src_key = None
+            self.set_dictionary(np.ascontiguousarray(D, dtype=dtype), None if weights is None else np.asarray(weights, dtype=dtype))
+            self._src_key = skey
+            return
+        self._src_key = None
         D3 = np.ascontiguousarray(D.reshape((D.shape[0], D.shape[1], -1)))
         code = dtype_code(D3.dtype)
         w = None if weights is None else np.ascontiguousarray(weights, dtype=D3.dtype)

@@ -272,7 +272,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             setups = [None] + [level_setup(l) for l in range(1, nbLevels)]
             for l in range(1, nbLevels):
                 Dl, wl = setups[l][0], setups[l][1]
-                engines[l].set_dictionary(np.ascontiguousarray(Dl, dtype=np.float64), np.asarray(wl, dtype=np.float64))
+                engines[l].set_dictionary(Dl, wl, dtype=np.float64)
                 timings.append(dict(level=l, variant='', kernel_ms=[0.0, 0.0, 0.0, 0.0], selections=0, duplicates=0, rounds=0, chunks=0))
             if memoryBudget is None:
                 memoryBudget = 0.6 * engines[0].mem_info()[1]      # (of the total: the cached engines already hold their workspaces)
