@@ -15,7 +15,7 @@ def _load(name):
     return json.load(open(path))
 
 
-@pytest.mark.parametrize('name', ['r02_bench_c2.json', 'r02_bench_c4.json', 'r02_bench_c5.json'])
+@pytest.mark.parametrize('name', ['r02_bench_c2.json', 'r02_bench_c4.json', 'r02_bench_c5.json', 'r03_bench_default.json'])
 def test_bench_line_has_the_contract_keys(name):
     d = _load(name)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
@@ -51,3 +51,22 @@ def test_config2_line_reports_what_section_8d_defines():
         assert abs(k['tflops'] - k['algorithmic_tflop'] / (k['ms'] * 1e-3)) <= 1e-6 * k['tflops']
     assert 0 < r['hbm_fraction'] < 0.1 and r['table_scan_equiv']['bytes_per_selection'] == 65536 * 256 * 4
     assert r['traffic'] is None or r['traffic'] > 0
+
+
+def test_default_line_carries_the_hierarchical_configurations():
+    """The default invocation (what the driver records) appends a bounded `secondary` object: BASELINE configs[3] with 17 and
+    with the literal 16 level-1 taps, configs[4] at its per-GPU share -- per-level rooflines, the rate with the residual
+    samples fetched, the reconstruction check."""
+    d = _load('r03_bench_default.json')
+    sec = d['secondary']
+    assert set(sec) == {'config4_17taps', 'config4_16taps', 'config5'}
+    for name, v in sec.items():
+        assert 'error' not in v and 'skipped' not in v, (name, v)
+        assert v['unit'] == 'atom-selections/s' and v['value'] > 0 and 0 < v['value_incl_residual_transfer'] <= v['value']
+        assert v['signals_per_gpu'] == (128 if name == 'config5' else 1024)
+        assert v['output_check']['device_energies_match_fetched_residuals'] and 'FAILED' not in v['output_check']
+        assert v['levels'][0]['bound'] == 'mfma' and 0 < v['levels'][0]['loop_frac'] <= 1
+        for l in v['levels'][1:]:
+            assert l['bound'] == 'latency' and 0 < l['latency_model']['frac'] <= 1 and 0 < l['hbm']['frac'] < 1
+    assert sec['config4_17taps']['output_check']['reconstructs'] is True and sec['config5']['output_check']['reconstructs'] is True
+    assert sec['config4_16taps']['output_check']['reconstructs'] is None          # (the reference itself reaches 2.9 dB on that hierarchy)
