@@ -63,6 +63,7 @@ class HscmpError(RuntimeError):
 
 
 ERR_ALLOC = -6
+ERR_UNSUPPORTED = -5
 
 
 _lib = None

@@ -1079,7 +1079,9 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 c = wave_argmax_first(c);
                 p_sel = c.i;
                 static_assert(Recorr::kScoreOnly, "the fused atom body resolves (k, c) itself");
-                nsel = 1;                  // (k, c) and the null test (:974) are resolved inside apply_atom
+                // (k, c) and the null test (:974) are resolved inside apply_atom.  No position at all: every score is NaN
+                // (a pursuit that diverged until the residual overflowed) -- nothing is selected and the loop ends
+                nsel = p_sel == INT_MAX ? 0 : 1;
             } else {
                 Cand<R> c; c.s = (R)-1; c.i = INT_MAX;
                 for (int i = tid; i < P.nseg; i += kThreads) {
@@ -1092,10 +1094,10 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 if (tid == 0) {
                     Cand<R> m = sh.cred[0];
                     for (int q = 1; q < kWaves; ++q) if (better(sh.cred[q], m)) m = sh.cred[q];
-                    const int sg = m.i;
+                    const int sg = m.i == INT_MAX ? 0 : m.i;          // (no segment compares: NaN scores of a diverged pursuit)
                     const R cc = sh.seg_c[sg];          // (non-fused policies keep coefficient / atom per segment)
                     sh.atom_t = sh.seg_t[sg]; sh.atom_k = sh.seg_k[sg]; sh.atom_c = cc;
-                    sh.nsel = (has_thres && !(fabs((double)cc) > thres)) ? 0 : 1;     // :974
+                    sh.nsel = (m.i == INT_MAX || (has_thres && !(fabs((double)cc) > thres))) ? 0 : 1;     // :974
                 }
                 sy.full();
                 nsel = sh.nsel;

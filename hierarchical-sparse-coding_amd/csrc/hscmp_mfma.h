@@ -861,6 +861,9 @@ template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
         if (lane < Tile::GA && k < P.K) {
             bc = Tile::template resolve<S4C>(L.dimg, rw, k, S4);
             if (HAS_W) { const R sw = bc * L.wts[k]; best.s = rabs(sw); } else best.s = rabs(bc);
+            // (a NaN -- diverged pursuit -- must not reach the reduction of the float64 build, whose comparisons would leave
+            //  the lanes with different winners; the float32 reduction orders bit patterns, where a NaN is the largest)
+            if constexpr (sizeof(R) == 8) { if (best.s != best.s) best.s = (R)INFINITY; }
             best.i = k;
         }
         best = wave_argmax_first(best);                     // (lane l holds atom GA*g + l: lanes in index order)

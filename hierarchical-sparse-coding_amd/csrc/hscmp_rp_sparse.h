@@ -638,12 +638,14 @@ template <typename R> struct RpSparse {
                 acc = rfma(G.r[(int64_t)g * F + (wf & 0xffff)], A.nzval[e], acc);
             }
             const R sc = score_of(acc, k, A.wts);
+            if (k == 0) bc = acc;                                             // (kept when no score compares: all NaN)
             if (sc > best.s) { best.s = sc; best.i = k; bc = acc; }           // ascending k per lane: '>' keeps the first of equals
         }
         const Cand<R> win = rp_wave_argmax(best);
         const int owner = __ffsll((long long)__ballot(best.i == win.i)) - 1;
         const R wc = wave_bcast(bc, owner);
-        if (lane == 0) { G.bc[t] = wc; G.bk[t] = win.i; }
+        // (win.i == INT_MAX: every score of the row is NaN -- a diverged pursuit; np.argmax gives atom 0)
+        if (lane == 0) { G.bc[t] = wc; G.bk[t] = win.i == INT_MAX ? 0 : win.i; }
     }
 
     // ---- rows p-(W-1) .. p+(W-1) from the (final) residual, reflect padded (:1018-1051): sparse window x sparse dictionary

@@ -605,6 +605,7 @@ __device__ __forceinline__ void sparse_rows(const DevParams& P, const State<R>& 
             if (sc > best.s) { best.s = sc; best.i = k; }
         }
         best = wave_argmax(best);
+        if (best.i == INT_MAX) best.i = 0;                       // every score of the row is NaN (a diverged pursuit): np.argmax gives 0
         if (lane == 0) { G.bc[t] = tab[row * K + best.i]; G.bk[t] = best.i; }
     }
     __syncthreads();

@@ -310,9 +310,18 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     raise
                 if device_epilogue:
                     slot_counts = (stats0 if nbLevels == 1 else last_stats)[(first if nbLevels == 1 else 0):(first if nbLevels == 1 else 0) + count, _native.STAT_SLOTS]
-                    self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents,
-                                          None if residual_all is None else residual_all[first:first + count],
-                                          None if energy_all is None else energy_all[first:first + count])
+                    try:
+                        self._device_epilogue(engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents,
+                                              None if residual_all is None else residual_all[first:first + count],
+                                              None if energy_all is None else energy_all[first:first + count])
+                    except _native.HscmpError as ex:
+                        # a shape outside the epilogue kernel's key layout (2^20 atoms / list entries, 2^24 samples): this chunk's
+                        # redistribution and residual are done on the host from the fetched slot lists, as with epilogue='host'
+                        if ex.code != _native.ERR_UNSUPPORTED:
+                            raise
+                        self._host_epilogue_chunk(engines, first, count, nbLevels, multilevelDict, returnDistributed, sequences, results, returnEvents,
+                                                  None if residual_all is None else residual_all[first:first + count],
+                                                  None if energy_all is None else energy_all[first:first + count])
                 first += count
             if device_epilogue:
                 if energy_all is not None:
@@ -342,6 +351,33 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             from .dataset import convertSparseMatricesToEvents
             out = out + ([convertSparseMatricesToEvents(c) for c in coefficients],)
         return out
+
+    def _host_epilogue_chunk(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, sequences, results, returnEvents,
+                             residual_out, energy_out):
+        """The chunk's epilogue on the host (:1556-1634, :1596-1611) from the slot lists of every level's engine -- level 0 holds
+        the whole batch, the levels above it this chunk.  Same results as the device epilogue (tests/test_hierarchical.py)."""
+        from . import _native
+        from .modeling import _slots_to_csc
+        levels = []
+        for l in range(nbLevels):
+            eng, off = engines[l], (first if l == 0 else 0)
+            st, sk, sa = eng.fetch_slots()
+            stats = eng.fetch_stats()
+            T = eng._batch[1]
+            levels.append([_slots_to_csc(st[off + b], sk[off + b], sa[off + b], int(stats[off + b, _native.STAT_SLOTS]), (T, eng.K), 1e-16)
+                           for b in range(count)])
+        for b in range(count):
+            cb = self._postprocessCoefficients([levels[l][b] for l in range(nbLevels)], multilevelDict, returnDistributed)
+            residual = np.asarray(self._calculateResidual(sequences[first + b], cb, multilevelDict), dtype=np.float64)
+            if residual_out is not None:
+                residual_out[b] = residual.reshape(residual_out[b].shape)
+            if energy_out is not None:
+                energy_out[b] = float(np.sum(np.square(residual)))
+            ev = None
+            if returnEvents:
+                from .dataset import convertSparseMatricesToEvents
+                ev = convertSparseMatricesToEvents(cb)
+            results[first + b] = (cb, None, ev)
 
     def _device_epilogue(self, engines, first, count, nbLevels, multilevelDict, returnDistributed, slot_counts, results, returnEvents, residual_out,
                          energy_out=None):

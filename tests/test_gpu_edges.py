@@ -87,6 +87,47 @@ def test_non_converging_pursuit_raises_instead_of_growing_forever():
         ConvolutionalMatchingPursuit().computeCoefficients(x, np.stack([D, D], axis=2), nbNonzeroCoefs=6)
 
 
+OVERFLOW_CASES = [((400, 1, 8, 16), 1), ((400, 1, 8, 16), 4), ((37, 2, 1, 11), 1), ((37, 2, 1, 11), 'auto'), ((300, 2, 5, 9), 1),
+                  ((300, 12, 6, 9, 'sparse'), 4), ((2000, 1, 32, 17), 4)]
+
+
+@pytest.mark.parametrize('shape,blocks', OVERFLOW_CASES)
+@pytest.mark.parametrize('rp', ['1', '0'])
+def test_overflowing_residual_ends_without_a_wild_index(shape, blocks, rp, monkeypatch):
+    """Float32 signals so large that the first coefficients overflow: correlations become inf / NaN, and every score of a
+    row can be NaN.  What the reference does then is not pinned (np.argmax over NaNs), but every loop family must still
+    hand valid positions and atoms on: the run ends with a stop reason or with the engine's 'does not converge' error --
+    not with a memory fault (which is how the per-row arg-max of the sparse policy used to end, INT_MAX as the atom)."""
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    from hsc_amd._native import HscmpError
+    if blocks != 1:
+        monkeypatch.setenv('HSCMP_RP', rp)
+    elif rp == '0':
+        pytest.skip('single arg-max rounds have one loop form')
+    rs = np.random.RandomState(5)
+    T, F, K, W = shape[:4]
+    if len(shape) > 4:
+        D = np.zeros((K, W, F), dtype=np.float32)
+        for k in range(K):
+            for _ in range(3):
+                D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5)
+    else:
+        D = rs.standard_normal((K, W, F)).astype(np.float32)
+    D /= np.sqrt(np.sum(np.square(D), axis=(1, 2), keepdims=True))
+    x = (rs.standard_normal((T, F)) * 1e38).astype(np.float32)
+    if F == 1:
+        x, D = x[:, 0], D[:, :, 0]
+    cmp = ConvolutionalMatchingPursuit()
+    try:
+        with np.errstate(all='ignore'):
+            cmp.computeCoefficients(x, D, nbNonzeroCoefs=50, nbBlocks=blocks, minCoefficients=None)
+    except HscmpError as ex:
+        assert 'does not converge' in str(ex)
+        return
+    t, k, c = cmp.lastResult.events[0]
+    assert len(t) > 0 and t.min() >= 0 and t.max() < T and k.min() >= 0 and k.max() < D.shape[0]
+
+
 def test_long_signals():
     """A million samples on the MFMA path (segment maxima at their largest segment size), and a multi-feature input
     longer than the row-bitmap / sparse-initial-correlation limit (262144 rows): generic initial correlation, sparse loop."""

@@ -78,7 +78,12 @@ def _draw(i):
 STALE_EDGE_SEEDS = [401, 2376, 2460, 2768, 3004, 3136, 4072, 4128, 4188, 4272, 4896, 5504]
 
 
-@pytest.mark.parametrize('i', list(range(N_CASES)) + [q for q in STALE_EDGE_SEEDS if q >= N_CASES])
+# a pursuit that diverges (filter longer than a third of the signal) until the float32 residual overflows: every score of a row
+# is NaN then, and the per-row arg-max over atoms must still name an atom (a soak run found the wild index it used to leave)
+DIVERGING_SEEDS = [301678]
+
+
+@pytest.mark.parametrize('i', list(range(N_CASES)) + [q for q in STALE_EDGE_SEEDS + DIVERGING_SEEDS if q >= N_CASES])
 def test_random_configuration_vs_oracle(i):
     from hsc_amd.modeling import ConvolutionalMatchingPursuit
     from hsc_amd._native import HscmpError

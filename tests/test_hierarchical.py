@@ -314,6 +314,55 @@ def test_device_epilogue_equals_host_epilogue(distributed, lds_keys, monkeypatch
 
 
 @pytest.mark.gpu
+def test_chunk_outside_the_epilogue_key_layout_is_finished_on_the_host(monkeypatch):
+    """hscmp_hierarchy_epilogue answers HSCMP_ERR_UNSUPPORTED for shapes outside its sort keys (2^20 atoms or list entries,
+    2^24 samples).  The default epilogue='device' then finishes that chunk on the host from the engines' slot lists instead of
+    raising: same coefficient matrices, events, residual samples and energies as epilogue='host' (the refusal is injected
+    here; any other error still surfaces)."""
+    from hsc_amd import _native
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+    z = _golden()
+    mld = _mld().withSingletonBases()
+    base = z['x']
+    xs = np.stack([base, base[::-1].copy(), (base * np.float32(1.3)), np.roll(base, 37), np.roll(base, -11)])
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    kw = dict(toleranceSnr=[15.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.9, memoryBudget=2.5e6)
+    ch, rh, _, eh = hcmp.computeCoefficientsBatch(xs, mld, epilogue='host', returnEvents=True, **kw)
+    calls = []
+
+    def refuse(self, *a, **k):
+        calls.append(1)
+        ex = _native.HscmpError('hscmp_hierarchy_epilogue failed (-5): shape outside the key layout')
+        ex.code = _native.ERR_UNSUPPORTED
+        raise ex
+
+    with monkeypatch.context() as m:
+        m.setattr(_native.Engine, 'hierarchy_epilogue', refuse)
+        cd, rd, _, ed = hcmp.computeCoefficientsBatch(xs, mld, epilogue='device', returnEvents=True, **kw)
+        ce, en, _ = hcmp.computeCoefficientsBatch(xs, mld, epilogue='device', residuals='energy', **kw)
+    assert len(calls) >= 2                                     # (several chunks, each refused)
+    assert rd.shape == rh.shape and np.array_equal(rd, rh)
+    assert np.allclose(en, np.sum(np.square(rh.reshape((xs.shape[0], -1)).astype(np.float64)), axis=1), rtol=1e-12, atol=0.0)
+    for b in range(xs.shape[0]):
+        for l in range(3):
+            a, h = scipy.sparse.csc_matrix(cd[b][l]), scipy.sparse.csc_matrix(ch[b][l])
+            assert a.shape == h.shape and (a != h).nnz == 0, (b, l)
+            assert (scipy.sparse.csc_matrix(ce[b][l]) != h).nnz == 0, (b, l)
+        assert np.array_equal(ed[b], eh[b]), b
+
+    def broken(self, *a, **k):
+        ex = _native.HscmpError('hscmp_hierarchy_epilogue failed (-3): something else')
+        ex.code = -3
+        raise ex
+
+    with monkeypatch.context() as m:
+        m.setattr(_native.Engine, 'hierarchy_epilogue', broken)
+        with pytest.raises(_native.HscmpError, match='something else'):
+            hcmp.computeCoefficientsBatch(xs, mld, epilogue='device', **kw)
+    hcmp.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', ['config4_dims', 'three_levels_dense_rows'])
 def test_level_input_buffer_is_clean_for_the_next_batch(case, monkeypatch):
     """Levels >= 1 read a dense [T, F] buffer that holds the previous level's coefficients.  Between batches the
