@@ -18,11 +18,12 @@ F32, F64 = 0, 1
 STAT_NNZ, STAT_DUPLICATES, STAT_ROUNDS, STAT_STOP, STAT_ITERATIONS, STAT_EVENTS, STAT_SLOTS, STAT_OFFSET = range(8)
 STAT_COUNT = 8
 STOP_NAMES = {0: 'running', 1: 'energy_eps', 2: 'nnz', 3: 'snr', 4: 'residual_scale', 5: 'empty',
-              6: 'callback', 7: 'capacity'}
-STOP_RUNNING, STOP_CAPACITY = 0, 7
+              6: 'callback', 7: 'capacity', 8: 'stalled', 9: 'group'}
+STOP_RUNNING, STOP_CAPACITY, STOP_STALLED, STOP_GROUP = 0, 7, 8, 9
+METHOD_CMP, METHOD_LOCOMP = 0, 1
 
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)
-EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream',
+EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream', 'hscmp_set_method',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
            'hscmp_update_inner_products', 'hscmp_table_open', 'hscmp_table_select', 'hscmp_table_update', 'hscmp_table_read', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_hierarchy_epilogue', 'hscmp_encode_batch',
            'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
@@ -86,6 +87,7 @@ def load_library():
     lib.hscmp_last_error.argtypes = [vp]
     lib.hscmp_last_error.restype = ctypes.c_char_p
     lib.hscmp_set_stream.argtypes = [vp, vp]
+    lib.hscmp_set_method.argtypes = [vp, ci]
     lib.hscmp_synchronize.argtypes = [vp]
     lib.hscmp_set_dictionary.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.hscmp_convolve1d.argtypes = [vp, vp, ci, ci, vp]
@@ -248,6 +250,10 @@ class Engine(object):
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.hscmp_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), 'hscmp_set_stream')
+
+    def set_method(self, method):
+        """METHOD_CMP (default) or METHOD_LOCOMP for the batch encodes that follow (sticky: reset it when done -- engines are shared)."""
+        self._check(self._lib.hscmp_set_method(self._h, int(method)), 'hscmp_set_method')
 
     def synchronize(self):
         self._check(self._lib.hscmp_synchronize(self._h), 'hscmp_synchronize')

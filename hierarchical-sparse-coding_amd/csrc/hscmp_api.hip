@@ -11,6 +11,7 @@
 #include "hscmp_sparse.h"
 #include "hscmp_rp.h"
 #include "hscmp_rp_sparse.h"
+#include "hscmp_locomp.h"
 #include "hscmp_epilogue.h"
 
 #include <cmath>
@@ -76,6 +77,9 @@ struct hscmp_ctx {
     bool timed_loop_only = false;   // the last timed launch was a hscmp_continue (no prepare / initial correlation)
     bool mfma_state = false;        // the batch's table-free state is the score-only form of the MFMA kernels
     bool rp_last = false;           // the last loop launch was the round-parallel form (hscmp_rp.h)
+    int method = 0;                 // hscmp_set_method: 0 = greedy pursuit (modeling.py:1053), 1 = LoCOMP (:1267)
+    bool locomp_state = false;      // the batch was encoded by the LoCOMP loop (hscmp_continue resumes it)
+    bool locomp_sparse = false;     // ... on the sparse policy (LocompSparse)
     const void* last_x_dev = nullptr;   // device address of the signals of the last encode (hscmp_hierarchy_epilogue reads them)
     // workspace arena of the entry points outside the batch encode (grow-only, lives as long as the context): slots
     // 0-7 the hierarchical epilogue, 8-15 the row-level entry points and the device-resident table
@@ -177,6 +181,14 @@ extern "C" void hscmp_destroy(hscmp_ctx* ctx)
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+extern "C" int hscmp_set_method(hscmp_ctx* ctx, int method)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_set_method: ctx is NULL");
+    if (method != HSCMP_METHOD_CMP && method != HSCMP_METHOD_LOCOMP) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_set_method: unknown method %d", method);
+    ctx->method = method;
+    return HSCMP_OK;
 }
 
 extern "C" int hscmp_set_stream(hscmp_ctx* ctx, void* hip_stream)
@@ -349,6 +361,7 @@ static int make_params_g(hscmp_ctx* ctx, int K, int W, int F, int B, int T, cons
     P.hmask = slot_hash_mask(P.cap);
     P.hash_min = kSlotHashMin;
     if (const char* v = getenv("HSCMP_SLOT_HASH_MIN")) P.hash_min = std::max(0, atoi(v));
+    if (ctx && ctx->method == HSCMP_METHOD_LOCOMP) P.hash_min = INT_MAX;        // (its atom body scans the slot list for the neighbourhood anyway)
     P.max_rounds = p->max_rounds;
     *out = P;
     return HSCMP_OK;
@@ -580,6 +593,37 @@ template <typename R> static int launch_iterate(hscmp_ctx* ctx, const DevParams&
     return HSCMP_OK;
 }
 
+// LoCOMP (hscmp_locomp.h): the table-free dense loop with the group re-fit as its atom body
+template <typename R> static int launch_iterate_locomp(hscmp_ctx* ctx, const DevParams& P0)
+{
+    using Pol = LocompRecorr<R>;
+    State<R> S = make_state<R>(ctx);
+    DevParams P = P0;
+    set_segments(P, Pol::kMaxSegments);
+    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P);
+    auto kern = iterate_kernel<R, Pol>;
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, typename Pol::Args{});
+    return HSCMP_OK;
+}
+
+// (dry: only tells whether the policy's LDS fits -- staged dictionary lists can be too long; the dense form runs then)
+template <typename R> static int launch_iterate_locomp_sparse(hscmp_ctx* ctx, const DevParams& P0, bool dry = false)
+{
+    using Pol = LocompSparse<R>;
+    State<R> S = make_state<R>(ctx);
+    DevParams P = P0;
+    set_segments(P, Pol::kMaxSegments);
+    const SparseArgs<R> A = sparse_args<R>(ctx, P.T, false);
+    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    if (lds > (size_t)158 * 1024) return -1;
+    if (dry) return 0;
+    auto kern = iterate_kernel<R, Pol>;
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
+    return HSCMP_OK;
+}
+
 // Slots of the previous level an input was scattered from (level chaining): the input then already sits in the
 // residual buffer and prepare only needs the energy.
 struct ChainSource { const int* slot_t; const int* slot_k; const double* slot_a; const int* stats; int cap, first, has_min; double minc; bool lists; int max_slots; };
@@ -612,7 +656,8 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     // reads (the generic / sparse kernels keep coefficient + atom instead).  Both are configured before anything is
     // queued; if either cannot run this shape, neither does.
     bool mf = false;
-    if (use_mfma(ctx, P.T) && mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag, true) == 0 &&
+    const bool loc = ctx->method == HSCMP_METHOD_LOCOMP;       // (its loop keeps coefficient + atom per position: no score-only state)
+    if (!loc && use_mfma(ctx, P.T) && mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag, true) == 0 &&
         mfma_launch_iterate<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag, true) == 0) {
         if (mfma_launch_corr_init<R>(ctx->stream, P, S, (const R*)ctx->d_Dfrag) != 0)
             return fail(ctx, HSCMP_ERR_HIP, "the MFMA initial correlation could not be launched");
@@ -641,14 +686,19 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
             return fail(ctx, HSCMP_ERR_HIP, "the MFMA loop could not be launched on the state of the MFMA initial correlation");
         mfi = true;
     }
-    const bool spl = !mfi && use_sparse_loop(ctx);
+    const bool spl = !mfi && !loc && use_sparse_loop(ctx);
     ctx->loop_kept_lists = spl && use_row_lists(ctx);
-    if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
+    ctx->locomp_state = loc;
+    const bool locs = loc && use_sparse_loop(ctx) && launch_iterate_locomp_sparse<R>(ctx, P, true) == 0;
+    ctx->locomp_sparse = locs;
+    if (loc) ctx->loop_kept_lists = locs && use_row_lists(ctx);
+    if (loc) { ctx->rp_last = false; int rc = locs ? launch_iterate_locomp_sparse<R>(ctx, P) : launch_iterate_locomp<R>(ctx, P); if (rc) return rc; }
+    else if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
     else if (!mfi) { int rc = launch_iterate<R>(ctx, P); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
-    ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
+    ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (loc ? (locs ? "locomp_dictlist" : "locomp") : mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
                    "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + ((mfi || spl) && ctx->rp_last ? std::string("_rp") : mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
     return HSCMP_OK;
 }
@@ -769,7 +819,11 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         if (rc != 0) return fail(ctx, HSCMP_ERR_HIP, "hscmp_continue: the MFMA loop could not be launched");
         mfi = true;
     }
-    if (!mfi && use_sparse_loop(ctx)) {
+    if (ctx->locomp_state) {
+        int rc = ctx->locomp_sparse ? (ctx->dtype == HSCMP_F32 ? launch_iterate_locomp_sparse<float>(ctx, P) : launch_iterate_locomp_sparse<double>(ctx, P))
+                                    : (ctx->dtype == HSCMP_F32 ? launch_iterate_locomp<float>(ctx, P) : launch_iterate_locomp<double>(ctx, P));
+        if (rc) return rc;
+    } else if (!mfi && use_sparse_loop(ctx)) {
         int rc = ctx->dtype == HSCMP_F32 ? launch_iterate_sparse<float>(ctx, P) : launch_iterate_sparse<double>(ctx, P);
         if (rc) return rc;
     } else if (!mfi) {

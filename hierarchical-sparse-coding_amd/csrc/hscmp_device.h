@@ -253,7 +253,9 @@ inline int cached_blocks_per_cu(const void* kern, int threads, size_t lds)
 enum { ST_NNZ = 0, ST_DUP = 1, ST_ROUNDS = 2, ST_STOP = 3, ST_ITERS = 4, ST_EVENTS = 5, ST_SLOTS = 6,
        ST_OFFSET = 7, ST_COUNT = 8 };
 enum { STOP_RUNNING = 0, STOP_ENERGY_EPS = 1, STOP_NNZ = 2, STOP_SNR = 3, STOP_SCALE = 4, STOP_EMPTY = 5,
-       STOP_CALLBACK = 6, STOP_CAPACITY = 7 };
+       STOP_CALLBACK = 6, STOP_CAPACITY = 7,
+       STOP_STALLED = 8,       // LoCOMP: an atom changed the residual energy by less than eps (modeling.py:1379-1383)
+       STOP_GROUP = 9 };       // LoCOMP: a neighbourhood larger than the kernel re-fits (kLocompMax): the host loop takes the signal
 
 template <typename R> struct State {
     const R* D;         // [K][W][F]

@@ -856,6 +856,7 @@ __device__ __forceinline__ R wave_window_energy(const DevParams& P, const Sig<R>
 template <typename R> struct GenericRecorr {
     static constexpr int kMaxSegments = kMaxSeg;
     static constexpr bool kFused = false;               // uses the step-by-step atom body of iterate_kernel
+    static constexpr bool kLocomp = false;              // (hscmp_locomp.h: LocompRecorr re-fits the atom's neighbourhood)
     static constexpr int kMinWavesPerSimd = 1;          // (register budget: no constraint)
     static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = false;           // keeps (coefficient, atom) per position
@@ -963,6 +964,11 @@ template <typename R> struct GenericRecorr {
 //   the workgroup.  kGroup = 4 (hscmp_mfma.h): four signals share a 1024-thread workgroup and ONE dictionary
 //   image in LDS; each signal synchronises its own four waves (SoftSync), the signals never wait for each other.
 // ------------------------------------------------------------------------------------------------
+// (hscmp_locomp.h: the atom body of LoCOMP, modeling.py:1314-1383)
+template <typename R, typename Pol, typename SH, typename SY>
+__device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy);
+
 template <typename R, typename Recorr>
 __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
 {
@@ -1294,6 +1300,11 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 const bool stop_now = Recorr::apply_atom(P, S, G, sh, A, plds, p, k, c, P.blocked != 0, sy, fc);
                 HSCMP_STAMP(12);                                   // the atom body, entry checks included
                 if (stop_now) { fused_stop = true; break; }
+                continue;
+            }
+            if constexpr (Recorr::kLocomp) {
+                locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy);
+                if (sh.skip || sh.converged) break;
                 continue;
             }
 

@@ -686,6 +686,7 @@ template <typename R> inline bool mfma_supported(int K, int W, int F)
 template <typename Tile, int S4C, bool HAS_W, int GS = 1> struct MfmaRecorr {
     static constexpr int kMaxSegments = kMfmaMaxSeg;
     static constexpr bool kFused = true;
+    static constexpr bool kLocomp = false;
     static constexpr int kGroup = GS;
     // -DHSCMP_QUAD_LOCKSTEP=1 (measurement only): barriers B1 and B4 of the atom body become hardware barriers across
     // the four signals of the workgroup, which lines their tiles up -- all serial phases then run together without a

@@ -621,6 +621,7 @@ template <typename R, bool PACKED = false> struct SparseRecorr {
     // LDS per workgroup is kept near 40 KB (4 workgroups per CU): the loop is latency bound, not compute bound
     static constexpr int kMaxSegments = PACKED ? 256 : 512;
     static constexpr bool kFused = false;
+    static constexpr bool kLocomp = false;
     static constexpr int kMinWavesPerSimd = PACKED ? 4 : 1;
     static constexpr int kEnergyWaves = PACKED ? kWaves / 2 : kWaves;
     static constexpr bool kScoreOnly = false;

@@ -38,7 +38,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             return ConvolutionalSparseCoder(D, ConvolutionalMatchingPursuit(device=self.device))
         if self.method == 'locomp':
             from .locomp import LoCOMP
-            return ConvolutionalSparseCoder(D, LoCOMP(device=self.device))
+            # (the reference's own pseudo-inverse per group: see LoCOMP.__init__; computeCoefficientsBatch runs the device loop)
+            return ConvolutionalSparseCoder(D, LoCOMP(device=self.device, refit='host'))
         if self.method in ('mptk-mp', 'mptk-cmp'):
             raise NotImplementedError("method='%s' needs the external MPTK toolkit, which this engine does not bind; "
                                       "use method='cmp' or 'locomp'" % self.method)
@@ -140,9 +141,6 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         """Release the per-level GPU engines (and their workspaces) of computeCoefficientsBatch."""
         for e in self.__dict__.pop('_engines', []):
             e.close()
-        pool = self.__dict__.pop('_host_loop_pool', None)
-        if pool is not None:
-            pool.shutdown(wait=True)          # (its threads' engines go with them)
 
     def computeCoefficientsBatch(self, sequences, multilevelDict, toleranceSnr=None, nbBlocks=1, singletonWeight=0.5,
                                  returnDistributed=True, chained=True, memoryBudget=None, epilogue='device', returnEvents=False,
@@ -165,27 +163,13 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         per-level kernel timings); with returnEvents=True a fourth item: per-signal event record arrays."""
         assert residuals in ('samples', 'energy')
         assert _is_multilevel_dict(multilevelDict)
-        if self.method != 'cmp':
-            # LoCOMP is a host-driven loop around the GPU hooks: signal by signal, several signals side by side -- every
-            # worker thread drives its own engine (context + stream, _native.default_engine), the GPU calls release the
-            # interpreter lock and overlap on the device
-            def one(b):
-                return self.computeCoefficients(sequences[b], multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
-                                                singletonWeight=singletonWeight, returnDistributed=returnDistributed)
-            nb = sequences.shape[0]
-            workers = max(1, min(int(os.environ.get('HSC_LOCOMP_WORKERS', '8')), nb))
-            if workers > 1:
-                # (the pool is kept: its threads own the engines, whose device buffers are then reused by the next batch)
-                pool = self.__dict__.get('_host_loop_pool')
-                if pool is None or pool._max_workers < workers:
-                    from concurrent.futures import ThreadPoolExecutor
-                    if pool is not None:
-                        pool.shutdown(wait=True)
-                    pool = self.__dict__['_host_loop_pool'] = ThreadPoolExecutor(max_workers=workers)
-                out = list(pool.map(one, range(nb)))
-            else:
-                out = [one(b) for b in range(nb)]
-            return [o[0] for o in out], np.stack([o[1] for o in out], axis=0), []
+        if self.method not in ('cmp', 'locomp'):
+            raise Exception('Unsupported sparse coding method: %s' % (self.method))
+        # method='locomp' (the reference's default, :1429): the same pipeline with every level's engine running the LoCOMP loop
+        # (csrc/hscmp_locomp.h).  A signal that meets a neighbourhood beyond the kernel's capacity at some level (stop reason
+        # 'group') is encoded again by the per-signal entry, whose host loop has no such limit.
+        locomp = self.method == 'locomp'
+        group_failed = set()
         from . import _native
         from .modeling import _compute_dtype, _slots_to_csc
         nbLevels = multilevelDict.getNbLevels()
@@ -202,7 +186,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         device_epilogue = chained and epilogue == 'device'
         assert residuals == 'samples' or device_epilogue, "residuals='energy' needs the device epilogue"
 
-        def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False):
+        def run_level(eng, encode, count, targetSnr, eps, maxEvents=4096, lazy=False, offset=0):
             """encode(params) with event-capacity regrowth; returns (list of csc, timing dict)"""
             # (an engine remembers the event capacity its last batch ended with: a stream of similar batches -- the bench,
             #  a dataset -- then starts with lists that fit, instead of growing them twice per level and batch)
@@ -225,6 +209,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                 eng.continue_rounds(0)
                 kernel_ms[2] += float(eng.last_kernel_ms()[2])
             eng._capacity_hint = ((T, nbBlocks), maxEvents)
+            group_failed.update(int(b) + offset for b in np.where(stats[:, _native.STAT_STOP] == _native.STOP_GROUP)[0])
             K = eng.K
             if device_epilogue:
                 out = None                                     # the coefficient slots stay on the device (hscmp_hierarchy_epilogue)
@@ -246,7 +231,11 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
             inputs = np.asarray(sequences)
             for level in range(nbLevels):
                 D, weights, targetSnr, _ = level_setup(level)
-                cmp = ConvolutionalMatchingPursuit(device=self.device)
+                if locomp:
+                    from .locomp import LoCOMP
+                    cmp = LoCOMP(device=self.device)
+                else:
+                    cmp = ConvolutionalMatchingPursuit(device=self.device)
                 res = cmp.computeCoefficientsBatch(inputs, D, toleranceSnr=targetSnr, nbBlocks=nbBlocks, weights=weights)
                 per_level[level] = res.coefficients
                 timings.append(dict(level=level, variant=res.variant, kernel_ms=[float(v) for v in res.kernel_ms],
@@ -255,6 +244,8 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                     inputs = np.stack([c.toarray() for c in res.coefficients], axis=0)      # [B, T, K_level] float64
         else:
             engines = self._level_engines(nbLevels)      # kept across calls: their workspaces are tens of GB
+            for e in engines:
+                e.set_method(_native.METHOD_LOCOMP if locomp else _native.METHOD_CMP)
             # level 0: the signals themselves, all B at once
             D, weights, targetSnr, eps = level_setup(0)
             dt = _compute_dtype(sequences.dtype, D.dtype)
@@ -296,7 +287,7 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                         # every input non-zero is explained at least once (by its singleton): size the lists for that
                         nin = int(last_stats[pfirst:pfirst + count, _native.STAT_SLOTS].max())
                         coefs, tm, last_stats = run_level(engines[l], lambda p, e=engines[l], pv=prev, pf=pfirst: e.encode_batch_from_level(pv, pf, count, 1e-16, p),
-                                                          count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64), lazy=True)
+                                                          count, targetSnr, eps, maxEvents=max(4096, nin + nin // 4 + 64), lazy=True, offset=first)
                         if coefs is not None:
                             per_level[l][first:first + count] = coefs
                         acc = timings[l]
@@ -324,6 +315,18 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
                                                   None if energy_all is None else energy_all[first:first + count])
                 first += count
             if device_epilogue:
+                for b in sorted(group_failed):
+                    cb, res_b = self.computeCoefficients(np.asarray(sequences[b]), multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
+                                                         singletonWeight=singletonWeight, returnDistributed=returnDistributed)
+                    ev = None
+                    if returnEvents:
+                        from .dataset import convertSparseMatricesToEvents
+                        ev = convertSparseMatricesToEvents(cb)
+                    results[b] = (cb, None, ev)
+                    if residual_all is not None:
+                        residual_all[b] = np.asarray(res_b, dtype=np.float64).reshape(residual_all[b].shape)
+                    if energy_all is not None:
+                        energy_all[b] = float(np.sum(np.square(np.asarray(res_b, dtype=np.float64))))
                 if energy_all is not None:
                     second = energy_all
                 else:
@@ -334,6 +337,9 @@ class HierarchicalConvolutionalMatchingPursuit(SparseApproximator):
         # host epilogue per signal (redistribution :1556-1594, residual :1596-1611), spread over the cores: the numpy
         # kernels it spends its time in release the interpreter lock
         def finish(b):
+            if b in group_failed:
+                return self.computeCoefficients(np.asarray(sequences[b]), multilevelDict, toleranceSnr=toleranceSnr, nbBlocks=nbBlocks,
+                                                singletonWeight=singletonWeight, returnDistributed=returnDistributed)
             levels = [per_level[l][b] for l in range(nbLevels)]
             levels = [_slots_to_csc(*c) if isinstance(c, tuple) else c for c in levels]
             cb = self._postprocessCoefficients(levels, multilevelDict, returnDistributed)

@@ -16,6 +16,7 @@ ConvolutionalMatchingPursuit.
 """
 import bisect
 import logging
+import os
 
 import numpy as np
 import scipy.sparse
@@ -29,8 +30,14 @@ logger = logging.getLogger(__name__)
 
 class LoCOMP(ConvolutionalMatchingPursuit):
 
-    def __init__(self, verbose=False, device=0):
+    def __init__(self, verbose=False, device=0, refit='device'):
+        """refit='device': the loop runs inside the greedy-loop kernel (csrc/hscmp_locomp.h), the group re-fit as float64 normal
+        equations.  refit='host': the host loop below over the device-resident table, the re-fit through np.linalg.pinv in the
+        dictionary's dtype exactly as the reference (:1326) -- what the per-signal hierarchical entry uses: a cascade of levels
+        amplifies the last-bit differences between two solvers wherever a group is ill-conditioned."""
         super(LoCOMP, self).__init__(verbose, device)
+        assert refit in ('device', 'host')
+        self.refit = refit
 
     def _initialInnerProducts(self, residual, D, dt):
         """:1293 innerProducts = convolve1d(residual, D, padding='same') -- computed and KEPT on the device
@@ -91,9 +98,43 @@ class LoCOMP(ConvolutionalMatchingPursuit):
             Dsup.append(s)
         return np.stack(Dsup), sequence[lo:hi + 1]
 
+    _method = _native.METHOD_LOCOMP      # computeCoefficientsBatch of the base class then runs the device loop of hscmp_locomp.h
+
+    def computeCoefficientsBatch(self, sequences, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None, nbBlocks=1,
+                                 minCoefficients=1e-16, weights=None, stopCondition=None, maxEvents=None):
+        """The B signals of `sequences` side by side, one workgroup each, through the LoCOMP atom body of the greedy-loop kernel
+        (csrc/hscmp_locomp.h: neighbourhood from the device slot list, normal equations of the group in LDS, group update and
+        re-correlation in the kernel).  A signal with a neighbourhood beyond the kernel's capacity (stop reason 'group') is
+        taken again by the host loop below; so is every call with a stopCondition (its argument there is the coefficient matrix,
+        :1397) or with verbose plots.  Returns a BatchResult like the base class."""
+        if stopCondition is not None or self.verbose or self.refit == 'host' or os.environ.get('HSCMP_LOCOMP_HOST') == '1':
+            return self._batch_on_host(sequences, D, nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks, minCoefficients, weights,
+                                       stopCondition)
+        res = super(LoCOMP, self).computeCoefficientsBatch(sequences, D, nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
+                                                           minCoefficients, weights, None, maxEvents)
+        again = np.where(res.stats[:, _native.STAT_STOP] == _native.STOP_GROUP)[0]
+        for b in again:
+            coef, residual = self._computeCoefficientsHost(np.asarray(sequences[b]), D, nbNonzeroCoefs, toleranceResidualScale, toleranceSnr,
+                                                           nbBlocks, minCoefficients, weights, None)
+            res.coefficients[b] = coef
+            res.residuals[b] = residual
+        return res
+
+    def _batch_on_host(self, sequences, D, *args):
+        from .modeling import BatchResult
+        out = [self._computeCoefficientsHost(np.asarray(s), D, *args) for s in sequences]
+        return BatchResult([o[0] for o in out], np.stack([o[1] for o in out], axis=0), None, None, None, 'locomp_host', None)
+
     def computeCoefficients(self, sequence, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
                             nbBlocks=1, minCoefficients=1e-16, weights=None, stopCondition=None):
         """hsc/modeling.py:1267-1425"""
+        res = self.computeCoefficientsBatch(np.asarray(sequence)[np.newaxis], D, nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
+                                            minCoefficients, weights, stopCondition)
+        return res.coefficients[0], res.residuals[0]
+
+    def _computeCoefficientsHost(self, sequence, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
+                                 nbBlocks=1, minCoefficients=1e-16, weights=None, stopCondition=None):
+        """hsc/modeling.py:1267-1425 as a host loop over the table entry points (hscmp_table_open / _select / _update)"""
         assert sequence.ndim == 1 or sequence.ndim == 2
         assert D.ndim == 2 or D.ndim == 3
         eps = np.finfo(D.dtype).eps

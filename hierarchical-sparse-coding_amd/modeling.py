@@ -283,7 +283,14 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         per_round = stopCondition is not None
         params = _native.make_params(nbNonzeroCoefs, toleranceResidualScale, toleranceSnr, nbBlocks,
                                      minCoefficients, eps, maxEvents, 1 if per_round else 0)
-        eng.encode_batch(x, params)
+        method = getattr(self, '_method', _native.METHOD_CMP)       # (hsc_amd.locomp.LoCOMP: the loop with the group re-fit)
+        if method != _native.METHOD_CMP:
+            eng.set_method(method)
+        try:
+            eng.encode_batch(x, params)
+        finally:
+            if method != _native.METHOD_CMP:
+                eng.set_method(_native.METHOD_CMP)                   # (engines are shared; a resumed batch keeps its own loop)
         kernel_ms = list(eng.last_kernel_ms())
         while True:
             if per_round:

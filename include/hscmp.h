@@ -53,8 +53,15 @@ typedef enum hscmp_stop {
     HSCMP_STOP_RESIDUAL_SCALE = 4, /* modeling.py:1145-1148 */
     HSCMP_STOP_EMPTY = 5,          /* modeling.py:1150-1153 */
     HSCMP_STOP_CALLBACK = 6,       /* modeling.py:1155-1158, decided by the host between rounds */
-    HSCMP_STOP_CAPACITY = 7        /* event buffer full: re-run with a larger max_events */
+    HSCMP_STOP_CAPACITY = 7,       /* event buffer full: re-run with a larger max_events */
+    HSCMP_STOP_STALLED = 8,        /* LoCOMP only, modeling.py:1379-1383: an atom changed the residual energy by less than eps */
+    HSCMP_STOP_GROUP = 9           /* LoCOMP only: a neighbourhood of more than 63 atoms (modeling.py:1222-1241); nothing of the
+                                      atom was applied -- the caller repeats such a signal through the table entry points */
 } hscmp_stop;
+
+/* which loop hscmp_encode_batch* / hscmp_continue run: ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053-1186)
+ * or LoCOMP.computeCoefficients (:1267-1425, the joint re-fit of every selected atom with its neighbourhood) */
+typedef enum hscmp_method { HSCMP_METHOD_CMP = 0, HSCMP_METHOD_LOCOMP = 1 } hscmp_method;
 
 /* keyword arguments of ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053) */
 typedef struct hscmp_params {
@@ -89,6 +96,12 @@ const char* hscmp_last_error(hscmp_ctx* ctx);
 /* Queue all work of this context on `hip_stream` (a hipStream_t; NULL = the context's own
  * stream).  hscmp_synchronize waits for it. */
 int hscmp_set_stream(hscmp_ctx* ctx, void* hip_stream);
+
+/* Method of the batch entry points from the next encode on (sticky; default HSCMP_METHOD_CMP).  Replaces the choice of the
+ * approximator class, modeling.py:1470-1487 (`method` of HierarchicalConvolutionalMatchingPursuit) / :1191 (class LoCOMP).
+ * Under HSCMP_METHOD_LOCOMP the statistic HSCMP_STAT_NNZ counts the stored non-zero coefficients (`coefficients.nnz`,
+ * :1368) and coefficients are compared with the reference at the tolerance of its pseudo-inverse, not bit for bit. */
+int hscmp_set_method(hscmp_ctx* ctx, int method);
 int hscmp_synchronize(hscmp_ctx* ctx);
 
 /* Dictionary D [K][W][F] and optional selection weights [K] (modeling.py:902-906), host

@@ -24,6 +24,11 @@ def _mld():
     return MultilevelDictionary.fromRawDictionaries(dicts, [int(s) for s in z['scales']])
 
 
+def _mld_first_level(mld):
+    from hsc_amd.dataset import MultilevelDictionary
+    return MultilevelDictionary.fromRawDictionaries([mld.getRawDictionary(0)], [int(_golden()['scales'][0])])
+
+
 def test_multilevel_dictionary_matches_reference():
     z = _golden()
     mld = _mld()
@@ -250,24 +255,42 @@ def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed,
 
 
 @pytest.mark.gpu
-def test_hierarchical_batch_with_locomp_runs_signal_by_signal():
-    """The batch entry point with the reference's default method ('locomp', a host loop around the GPU hooks)."""
-    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit
+def test_hierarchical_batch_with_locomp_runs_the_device_loop_on_every_level():
+    """The batch entry point with the reference's default method ('locomp'): the chained pipeline of method='cmp' with every
+    level's engine on the LoCOMP loop (csrc/hscmp_locomp.h).  Deterministic, the same from the device and the host epilogue,
+    the residual is the signal minus the reconstruction of the returned code, and level 0 equals the stand-alone batch LoCOMP.
+    (Against the per-signal entry -- the reference's own pseudo-inverse on the host -- a cascade of levels only agrees loosely:
+    the two solvers differ in the last bits, and an ill-conditioned group downstream amplifies that; see DESIGN.md.)"""
+    from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, LoCOMP
     z = _golden()
     mld = _mld().withSingletonBases()
     rs = np.random.RandomState(2)
     xs = np.stack([z['x'], (z['x'][::-1]).copy()] + [np.roll(z['x'], int(s)) * np.float32(a) for s, a in zip(rs.randint(1, 200, 10), rs.uniform(0.5, 2.0, 10))])
     hcmp = HierarchicalConvolutionalMatchingPursuit(method='locomp')
     kw = dict(toleranceSnr=[10.0, 20.0, 20.0], nbBlocks=4, singletonWeight=0.5)
-    # (twelve signals over the worker threads of the batch path, each with its own engine; twice: the pool is reused)
     coefs, residuals, timings = hcmp.computeCoefficientsBatch(xs, mld, **kw)
+    assert all('locomp' in t['variant'] for t in timings)
     coefs2, residuals2, _ = hcmp.computeCoefficientsBatch(xs, mld, **kw)
-    assert np.array_equal(residuals, residuals2)
+    coefs3, residuals3, _ = hcmp.computeCoefficientsBatch(xs, mld, epilogue='host', **kw)
+    assert np.array_equal(residuals, residuals2) and np.array_equal(residuals, residuals3)
     for b in range(xs.shape[0]):
-        c1, r1 = hcmp.computeCoefficients(xs[b], mld, **kw)
         for l in range(3):
-            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(c1[l])).nnz == 0
-        assert np.array_equal(residuals[b], r1)
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs2[b][l])).nnz == 0
+            assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs3[b][l])).nnz == 0
+        r = hcmp._calculateResidual(xs[b], coefs[b], mld)
+        assert np.allclose(residuals[b], r, rtol=0.0, atol=1e-9)
+    # level 0 alone (not distributed: the last level's singleton columns are what returnDistributed hands back)
+    first, _, _ = hcmp.computeCoefficientsBatch(xs, _mld_first_level(mld), toleranceSnr=[10.0], nbBlocks=4, singletonWeight=0.5, returnDistributed=False)
+    D0 = mld.getRawDictionary(0)
+    alone = LoCOMP().computeCoefficientsBatch(xs, D0, toleranceSnr=10.0, nbBlocks=4, weights=np.ones((D0.shape[0],), dtype=D0.dtype))
+    for b in range(xs.shape[0]):
+        assert (scipy.sparse.csc_matrix(first[b][0]) != alone.coefficients[b]).nnz == 0
+    # loose agreement with the per-signal entry: the same number of level-0 atoms within a quarter, on every signal
+    for b in range(0, xs.shape[0], 3):
+        c1, _ = hcmp.computeCoefficients(xs[b], mld, returnDistributed=False, **kw)
+        cb, _, _ = hcmp.computeCoefficientsBatch(xs[b:b + 1], mld, returnDistributed=False, **kw)
+        assert abs(cb[0][2].nnz - c1[2].nnz) <= max(4, c1[2].nnz // 4)
+    hcmp.close()
 
 
 @pytest.mark.gpu

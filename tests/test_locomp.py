@@ -42,7 +42,11 @@ def _check(coder, name):
 
 
 class _OracleHooks(object):
-    """Mixin replacing the GPU-backed hooks by the CPU oracle."""
+    """Mixin replacing the GPU-backed hooks by the CPU oracle (and keeping the call on the host loop: the product's
+    computeCoefficients runs the device loop of csrc/hscmp_locomp.h, the host loop is what takes over from it)."""
+
+    def computeCoefficients(self, *args, **kw):
+        return self._computeCoefficientsHost(*args, **kw)
 
     def _selectBestAtoms(self, innerProducts, filterWidth, nbBlocks=1, offset=False, nullCoeffThres=0.0, weights=None):
         from oracle import hsc_oracle as orc
@@ -74,8 +78,112 @@ def test_locomp_host_loop_with_oracle_hooks(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', _names())
 def test_locomp_gpu_vs_reference_golden(name):
+    """The device loop (neighbourhood, re-fit, group update inside the greedy-loop kernel) against the reference's goldens."""
     from hsc_amd.modeling import LoCOMP
+    coder = LoCOMP()
+    _check(coder, name)
+    assert 'locomp' in coder.lastResult.variant and 'group' not in coder.lastResult.stop_reasons()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', _names())
+def test_locomp_host_loop_over_the_table_entry_points(name, monkeypatch):
+    """The host loop (hscmp_table_open / _select / _update + np.linalg.pinv) that takes over when a neighbourhood exceeds
+    the kernel's capacity or a stopCondition is given: the same goldens."""
+    from hsc_amd.modeling import LoCOMP
+    monkeypatch.setenv('HSCMP_LOCOMP_HOST', '1')
     _check(LoCOMP(), name)
+
+
+def _planted(T, K, W, F, dtype, seed, natoms, sparse_dictionary=False):
+    rs = np.random.RandomState(seed)
+    if sparse_dictionary:
+        D = np.zeros((K, W, F))
+        for k in range(K):
+            for _ in range(3):
+                D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+    else:
+        D = rs.standard_normal((K, W, F))
+    D /= np.sqrt(np.sum(np.square(D), axis=(1, 2), keepdims=True))
+    x = 0.01 * rs.standard_normal((T, F)) * (rs.rand(T, F) < (0.05 if sparse_dictionary else 1.0))
+    for _ in range(natoms):
+        k, t = rs.randint(0, K), rs.randint(0, T - W)
+        x[t:t + W] += rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0]) * D[k]
+    D, x = D.astype(dtype), x.astype(dtype)
+    return (x[:, 0], D[:, :, 0]) if F == 1 else (x, D)
+
+
+BATCH_CASES = [
+    # T, K, W, F, dtype, planted atoms, keyword arguments, sparse dictionary
+    (700, 12, 16, 1, np.float32, 30, dict(toleranceSnr=20.0), False),
+    (700, 12, 16, 1, np.float64, 30, dict(toleranceSnr=25.0, nbBlocks=4), False),
+    (900, 20, 9, 1, np.float32, 60, dict(nbNonzeroCoefs=40, nbBlocks='auto'), False),
+    (400, 6, 8, 3, np.float64, 25, dict(toleranceSnr=20.0, nbBlocks=3), False),
+    (600, 10, 9, 12, np.float64, 40, dict(toleranceSnr=25.0, nbBlocks=4), True),
+    (600, 10, 9, 12, np.float64, 40, dict(nbNonzeroCoefs=30), True),
+    (500, 8, 17, 1, np.float32, 25, dict(toleranceSnr=15.0, nbBlocks=2, weights='w'), False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', range(len(BATCH_CASES)))
+def test_locomp_device_loop_vs_host_loop(case, monkeypatch):
+    """A batch of related signals through the device loop (csrc/hscmp_locomp.h: one workgroup per signal, neighbourhood + float64
+    normal equations + group update in the kernel) against the host loop over the table entry points (np.linalg.pinv as in the
+    reference): same support, same stop, coefficients and residual within the tolerance of the two solvers.  Dense and sparse
+    (LocompSparse) policies, single arg-max and blocked rounds, weights."""
+    from hsc_amd.modeling import LoCOMP
+    T, K, W, F, dtype, natoms, kw, sp = BATCH_CASES[case]
+    x, D = _planted(T, K, W, F, dtype, 100 + case, natoms, sp)
+    kw = dict(kw)
+    if kw.get('weights') == 'w':
+        kw['weights'] = np.linspace(0.6, 1.0, K).astype(dtype)
+    rs = np.random.RandomState(case)
+    xs = np.stack([x, (0.5 * x).astype(dtype), x[::-1].copy(), (x + 0.02 * rs.standard_normal(x.shape)).astype(dtype), np.zeros_like(x)])
+    dev = LoCOMP()
+    res = dev.computeCoefficientsBatch(xs, D, **kw)
+    assert 'locomp' in res.variant and (not sp or 'dictlist' in res.variant)
+    reasons = res.stop_reasons()
+    assert reasons.count('group') <= 1                         # (a noisy multi-feature member may outgrow the kernel's group: host loop)
+    again = dev.computeCoefficientsBatch(xs, D, **kw)
+    monkeypatch.setenv('HSCMP_LOCOMP_HOST', '1')
+    tol = 2e-5 if dtype == np.float32 else 1e-9
+    for b in range(xs.shape[0]):
+        assert (res.coefficients[b] != again.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], again.residuals[b])
+        ch, rh = LoCOMP().computeCoefficients(xs[b], D, **kw)
+        if reasons[b] == 'group':
+            assert (res.coefficients[b] != ch).nnz == 0 and np.array_equal(res.residuals[b], rh)
+            continue
+        a, h = res.coefficients[b].tocsc(), ch.tocsc()
+        assert a.shape == h.shape and a.nnz == h.nnz and np.array_equal(a.indices, h.indices) and np.array_equal(a.indptr, h.indptr), (case, b)
+        scale = max(1.0, float(np.max(np.abs(h.data))) if h.nnz else 1.0)
+        assert (float(np.max(np.abs(a.data - h.data))) if h.nnz else 0.0) <= tol * scale, (case, b)
+        assert float(np.max(np.abs(res.residuals[b].astype(np.float64) - rh))) <= 10 * tol * scale, (case, b)
+
+
+@pytest.mark.gpu
+def test_locomp_neighbourhood_beyond_the_kernel_capacity_goes_to_the_host_loop():
+    """More than 63 previously selected atoms around a new one (short filters, many atoms per position, a demanding SNR):
+    the kernel stops the signal with reason 'group' before applying anything of that atom, and the batch entry repeats the
+    signal on the host loop -- the result is the host loop's, the other signals keep the device loop's."""
+    from hsc_amd.modeling import LoCOMP
+    rs = np.random.RandomState(4)
+    K, W, T, F = 40, 5, 60, 12                                # (a neighbourhood spans ~3W x F = 180 dimensions: room for > 63 atoms)
+    D = rs.standard_normal((K, W, F)).astype(np.float64)
+    D /= np.sqrt(np.sum(D ** 2, axis=(1, 2), keepdims=True))
+    dense = rs.standard_normal((T, F))
+    sparse = np.zeros((T, F)); sparse[20:25] = D[3]; sparse[40:45] = -2.0 * D[7]
+    xs = np.stack([dense, sparse])
+    coder = LoCOMP()
+    kw = dict(toleranceSnr=50.0, nbNonzeroCoefs=3000)
+    res = coder.computeCoefficientsBatch(xs, D, **kw)
+    assert res.stop_reasons()[0] == 'group' and res.stop_reasons()[1] != 'group'
+    host = LoCOMP(refit='host')
+    ch, rh = host.computeCoefficients(dense, D, **kw)
+    assert (res.coefficients[0] != ch).nnz == 0 and np.array_equal(res.residuals[0], rh)
+    cs, rsd = host.computeCoefficients(sparse, D, **kw)
+    assert np.array_equal(res.coefficients[1].tocsc().indices, cs.tocsc().indices)
+    assert float(np.max(np.abs(res.coefficients[1].tocsc().data - cs.tocsc().data))) <= 1e-9
 
 
 @pytest.mark.gpu
