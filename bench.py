@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'], help='arithmetic type of the path (BASELINE config 2 is f32)')
     ap.add_argument('--level1-taps', type=int, default=17, help='config 4: taps of the level-1 dictionary (17 = scales [64, 80], the '
                     'nearest shape whose hierarchy is self-consistent; 16 = the literal BASELINE shape, see hsc_amd.synth.make_hierarchy)')
+    ap.add_argument('--method', default='cmp', choices=['cmp', 'locomp'], help="configs 4 / 5: method of the hierarchical encoder ('locomp' is the "
+                    "reference's default, modeling.py:1429; BASELINE's metric is quoted on the greedy loop, 'cmp')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-transfers', action='store_true', help='skip the PCIe-inclusive leg')
     ap.add_argument('--no-secondary', action='store_true', help='config 2 only: skip the bounded runs of the hierarchical configurations (configs 4 / 5)')

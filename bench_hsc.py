@@ -83,7 +83,7 @@ def level_roofline(Dl, T, B, tm, nbBlocks):
     elif not rp:
         # (co-resident workgroups overlap: two per CU, four in the packed build -- up to 1024 signals walk side by side)
         model_s = atoms / B * SEQ_ROUND_TRIPS_PER_ATOM * IC_HIT_LATENCY_S * max(1.0, B / 1024.0)
-    out = dict(bound='latency', kernel='iterate_rp_kernel<RpSparse>' if rp else 'iterate_kernel<SparseRecorr>',
+    out = dict(bound='latency', kernel='iterate_rp_kernel<RpSparse>' if rp else 'iterate_kernel<LocompSparse>' if 'locomp' in tm['variant'] else 'iterate_kernel<SparseRecorr>',
                atoms_per_s=atoms / loop_s, us_per_atom_per_signal=1e6 * loop_s * B / atoms,
                dictionary_nonzeros_per_atom=nz,
                latency_model={'round_trip_s': IC_HIT_LATENCY_S, 'dependent_round_trips': ('%d per round' % RP_ROUND_TRIPS) if rp else ('%d per atom' % SEQ_ROUND_TRIPS_PER_ATOM),
@@ -155,7 +155,7 @@ def run(args, ctx):
     mlds, xs, kw, desc = build_workload(config, B, T, rank * B, args.level1_taps)
     nlev = mlds.getNbLevels()
     x_dev = torch.from_numpy(xs).to(dev)
-    hcmp = HierarchicalConvolutionalMatchingPursuit(method='cmp', device=ctx['dev_index'])
+    hcmp = HierarchicalConvolutionalMatchingPursuit(method=getattr(args, 'method', 'cmp'), device=ctx['dev_index'])
 
     # Timed step: inputs resident in HBM, and -- as in the config-2 bench -- the residual SAMPLES stay there too: the
     # encoder returns the coefficient matrices and the residual energy of every signal (summed on the device), which is what
@@ -234,7 +234,7 @@ def run(args, ctx):
         'value': nsel_total * steps / elapsed_max, 'unit': 'atom-selections/s',
         'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed_max / steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (level 0) / f64 (levels >= 1)', 'data': 'synthetic',
-        'config': {'workload': desc, 'signals_per_gpu': B, 'T': T, 'levels': nlev, 'selections_per_step': nsel_total,
+        'config': {'workload': desc, 'method': getattr(args, 'method', 'cmp'), 'signals_per_gpu': B, 'T': T, 'levels': nlev, 'selections_per_step': nsel_total,
                    'kernel_ms_per_step': kernel_ms, 'output_check': check},
         'roofline': {'bound': 'mfma', 'kernel': 'level-0 greedy loop (iterate_kernel, blocked selection)', 'achieved': l0['loop_tflops'],
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': l0['loop_frac'], 'kernel_ms': l0['loop_ms'],

@@ -80,6 +80,7 @@ struct hscmp_ctx {
     int method = 0;                 // hscmp_set_method: 0 = greedy pursuit (modeling.py:1053), 1 = LoCOMP (:1267)
     bool locomp_state = false;      // the batch was encoded by the LoCOMP loop (hscmp_continue resumes it)
     bool locomp_sparse = false;     // ... on the sparse policy (LocompSparse)
+    bool locomp_mfma = false;       // ... with the re-correlations on the matrix cores (LocompMfma)
     const void* last_x_dev = nullptr;   // device address of the signals of the last encode (hscmp_hierarchy_epilogue reads them)
     // workspace arena of the entry points outside the batch encode (grow-only, lives as long as the context): slots
     // 0-7 the hierarchical epilogue, 8-15 the row-level entry points and the device-resident table
@@ -607,6 +608,35 @@ template <typename R> static int launch_iterate_locomp(hscmp_ctx* ctx, const Dev
     return HSCMP_OK;
 }
 
+// single-feature float32 with a dictionary image (hscmp_set_dictionary built it): the re-correlations on the matrix cores
+template <int S4C, bool HAS_W> static int launch_iterate_locomp_mfma_t(hscmp_ctx* ctx, const DevParams& P0, bool dry)
+{
+    using Pol = LocompMfma<S4C, HAS_W>;
+    State<float> S = make_state<float>(ctx);
+    DevParams P = P0;
+    set_segments(P, Pol::kMaxSegments);
+    MfmaArgs A;
+    A.dimg = (const float*)ctx->d_Dfrag; A.G = mfma_groups(P.K); A.S4 = S4C; A.has_w = HAS_W ? 1 : 0;
+    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    if (lds > (size_t)158 * 1024) return -1;
+    if (dry) return 0;
+    auto kern = iterate_kernel<float, Pol>;
+    HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
+    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
+    return HSCMP_OK;
+}
+static int launch_iterate_locomp_mfma(hscmp_ctx* ctx, const DevParams& P, bool dry)
+{
+    if (ctx->dtype != HSCMP_F32 || ctx->F != 1 || !ctx->d_Dfrag || getenv("HSCMP_LOCOMP_NO_MFMA")) return -1;
+    const bool w = ctx->d_w != nullptr;
+    switch (mfma_chunks(P.W)) {
+    case 8: return w ? launch_iterate_locomp_mfma_t<8, true>(ctx, P, dry) : launch_iterate_locomp_mfma_t<8, false>(ctx, P, dry);
+    case 4: return w ? launch_iterate_locomp_mfma_t<4, true>(ctx, P, dry) : launch_iterate_locomp_mfma_t<4, false>(ctx, P, dry);
+    case 2: return w ? launch_iterate_locomp_mfma_t<2, true>(ctx, P, dry) : launch_iterate_locomp_mfma_t<2, false>(ctx, P, dry);
+    default: return -1;
+    }
+}
+
 // (dry: only tells whether the policy's LDS fits -- staged dictionary lists can be too long; the dense form runs then)
 template <typename R> static int launch_iterate_locomp_sparse(hscmp_ctx* ctx, const DevParams& P0, bool dry = false)
 {
@@ -673,8 +703,10 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
                            ctx->d_rl_cnt, ctx->d_rl_f, kRowListCap);
     }
     const bool spi = !mf && use_sparse_init(ctx, P.T);
+    // (LoCOMP on the matrix cores: its loop kernel starts with the initial correlation -- see LocompMfma::prologue)
+    const bool own_init = loc && !spi && !use_sparse_loop(ctx) && launch_iterate_locomp_mfma(ctx, P, true) == 0;
     if (spi) { int rc = launch_corr_init_sparse<R>(ctx, P); if (rc) return rc; }
-    if (!mf && !spi) {
+    if (!mf && !spi && !own_init) {
         dim3 grid((P.T + kThreads - 1) / kThreads, P.B);
         hipLaunchKernelGGL((corr_init_generic_kernel<R, false>), grid, dim3(kThreads), 0, ctx->stream, P, S,
                            (const R*)ctx->d_resid, P.off, P.T, (R*)nullptr);
@@ -692,13 +724,19 @@ template <typename R> static int run_encode(hscmp_ctx* ctx, const DevParams& P, 
     const bool locs = loc && use_sparse_loop(ctx) && launch_iterate_locomp_sparse<R>(ctx, P, true) == 0;
     ctx->locomp_sparse = locs;
     if (loc) ctx->loop_kept_lists = locs && use_row_lists(ctx);
-    if (loc) { ctx->rp_last = false; int rc = locs ? launch_iterate_locomp_sparse<R>(ctx, P) : launch_iterate_locomp<R>(ctx, P); if (rc) return rc; }
+    const bool locm = loc && !locs && own_init;
+    ctx->locomp_mfma = locm;
+    if (loc) {
+        ctx->rp_last = false;
+        int rc = locs ? launch_iterate_locomp_sparse<R>(ctx, P) : locm ? launch_iterate_locomp_mfma(ctx, P, false) : launch_iterate_locomp<R>(ctx, P);
+        if (rc) return rc;
+    }
     else if (spl) { int rc = launch_iterate_sparse<R>(ctx, P); if (rc) return rc; }
     else if (!mfi) { int rc = launch_iterate<R>(ctx, P); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->timed = true; ctx->timed_loop_only = false;
-    ctx->variant = std::string(mf ? "mfma" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (loc ? (locs ? "locomp_dictlist" : "locomp") : mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
+    ctx->variant = std::string(mf ? "mfma" : own_init ? "own" : spi ? (ctx->d_nzptr ? "dictlist" : "sparse") : "generic") + "_init+" + (loc ? (locs ? "locomp_dictlist" : locm ? "locomp_mfma" : "locomp") : mfi ? "mfma" : spl ? (ctx->d_nzptr ? "dictlist" : "gathered") : "generic") +
                    "_loop_" + (sizeof(R) == 4 ? "f32" : "f64") + ((mfi || spl) && ctx->rp_last ? std::string("_rp") : mfi && mfma_last_group() > 1 ? "_x" + std::to_string(mfma_last_group()) : std::string());
     return HSCMP_OK;
 }
@@ -820,7 +858,8 @@ extern "C" int hscmp_continue(hscmp_ctx* ctx, int max_rounds)
         mfi = true;
     }
     if (ctx->locomp_state) {
-        int rc = ctx->locomp_sparse ? (ctx->dtype == HSCMP_F32 ? launch_iterate_locomp_sparse<float>(ctx, P) : launch_iterate_locomp_sparse<double>(ctx, P))
+        int rc = ctx->locomp_mfma ? launch_iterate_locomp_mfma(ctx, P, false) :
+                 ctx->locomp_sparse ? (ctx->dtype == HSCMP_F32 ? launch_iterate_locomp_sparse<float>(ctx, P) : launch_iterate_locomp_sparse<double>(ctx, P))
                                     : (ctx->dtype == HSCMP_F32 ? launch_iterate_locomp<float>(ctx, P) : launch_iterate_locomp<double>(ctx, P));
         if (rc) return rc;
     } else if (!mfi && use_sparse_loop(ctx)) {

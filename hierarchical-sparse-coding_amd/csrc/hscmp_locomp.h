@@ -17,6 +17,7 @@
 // Parity is at tolerance level by construction (the reference's pseudo-inverse is an SVD in the dictionary's dtype).
 #pragma once
 #include "hscmp_kernels.h"
+#include "hscmp_mfma.h"
 #include "hscmp_sparse.h"
 
 namespace hscmp {
@@ -43,6 +44,10 @@ template <typename R> struct LocompLds {
 // the dense table-free loop (GenericRecorr) with the group re-fit as its atom body
 template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kLocomp = true;
+    static constexpr bool kWaveApply = true;            // (no per-policy residual update: short atoms go through one wave)
+    static constexpr bool kUnionRows = false;
+    static constexpr bool kOwnInit = false;
+    static __device__ __forceinline__ void run_span(const DevParams&, const Sig<R>&, const typename GenericRecorr<R>::Args&, char*, int, int) {}
     using Base = GenericRecorr<R>;
     using Args = typename Base::Args;
     static size_t extra_lds_bytes(const DevParams& P) { return Base::extra_lds_bytes(P) + sizeof(LocompLds<R>) + 16; }
@@ -57,6 +62,9 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
 // the per-row lists of non-zero cells current, the re-correlation forms the non-zero products only
 template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
+    static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
+    static constexpr bool kUnionRows = false;
+    static __device__ __forceinline__ void run_span(const DevParams&, const Sig<R>&, const SparseArgs<R>&, char*, int, int) {}
     using Base = SparseRecorr<R, false>;
     using Args = typename Base::Args;
     static size_t policy_bytes(const DevParams& P, const Args& A) { return ((Base::extra_lds_bytes(P, A) + 15) / 16) * 16; }
@@ -71,6 +79,155 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static __device__ __forceinline__ void before_runs(const Args& A, char* lds)
     {
         if (ltid() == 0) sparse_lds_view<R>(lds, A.caps).ctl[3] = 0;
+    }
+};
+
+// Single-feature float32 signals: the re-correlation of a group atom's 2W-1 rows on the matrix cores.  The loop keeps
+// (coefficient, atom) per position like the dense form, so a tile's result -- the row's best SCORE and the 32-atom group that holds the
+// first atom attaining it (mfma_tile_score) -- is resolved right away: one chain per lane over that group's atoms (the pinned
+// sequential chain, as the dense form computes it), arg-max with the lowest atom among equals.
+// LDS behind the control block: [window | group hints | per-wave resolve windows][LocompLds][dictionary image | weights]
+template <int S4C, bool HAS_W> struct LocompMfma {
+    using R = float;
+    static constexpr int kMaxSegments = kMaxSeg;
+    static constexpr bool kFused = false;
+    static constexpr bool kLocomp = true;
+    static constexpr bool kWaveApply = true;
+    static constexpr int kMinWavesPerSimd = 1;
+    static constexpr int kEnergyWaves = kWaves;
+    static constexpr bool kScoreOnly = false;
+    static constexpr int kGroup = 1;
+    static constexpr int TP = 32;
+    using Shared = IterSharedT<float, kMaxSeg>;
+    using Args = MfmaArgs;
+    using Sync = HwSync;
+    static __device__ __forceinline__ Sync make_sync(Shared&) { return Sync(); }
+    static __device__ __forceinline__ void prologue_shared(const DevParams&, const State<R>&, const Args&, char*) {}
+    static __device__ __forceinline__ int signal_lds_offset(const DevParams&, const Args&) { return 0; }
+    static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*, int) {}
+    static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, int&, R&) {}
+    static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
+    static __device__ __forceinline__ void on_atom(const DevParams&, const State<R>&, const Args&, char*, int, int) {}
+    static __device__ __forceinline__ bool update_residual(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, R,
+                                                           int, int, int, R&, R&) { return false; }
+    static __device__ __forceinline__ bool window_partials(const DevParams&, const Sig<R>&, const Args&, char*, int, int, R&) { return false; }
+    static __device__ __forceinline__ bool wave_window_listed(const DevParams&, const Sig<R>&, const Args&, char*, int, int, int, int, R&) { return false; }
+    static __device__ __forceinline__ bool row_results(const DevParams&, const Args&, char*, int, const int*&, const R*&, const R*&, int&, int&) { return false; }
+    static __device__ __forceinline__ bool residual_copy_in_lds(const Args&, char*) { return false; }
+    static __device__ __forceinline__ void before_runs(const Args&, char*) {}
+
+    // rows of one re-correlation: 2W-1 around one atom, or the union over a group of interior atoms -- their positions lie within
+    // [p - W, p + W] of the selected atom (:1228-1236), so at most 4W-1 rows
+    static constexpr bool kUnionRows = true;
+    static __host__ __device__ int max_tiles(int W) { return (4 * W - 1 + TP - 1) / TP; }
+    static __host__ __device__ int win_floats(int W) { return max_tiles(W) * TP + 8 * S4C + 32; }        // (a multiple of 4)
+    static __host__ __device__ size_t front_bytes(int W)
+    {
+        // four copies of the window, copy c shifted by c samples: row r's window starts 16-byte aligned in copy r & 3
+        return ((4 * (size_t)win_floats(W) + (size_t)max_tiles(W) * TP) * sizeof(float) + 15) / 16 * 16;
+    }
+    static __host__ __device__ size_t image_bytes(const Args& A) { return ((size_t)A.G * S4C * 256 + 32 * (size_t)A.G) * sizeof(float); }
+    static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return front_bytes(P.W) + (sizeof(LocompLds<R>) + 15) / 16 * 16 + image_bytes(A); }
+    struct Lay { float* win; int* hint; float* dimg; float* wts; int wf; };
+    static __device__ __forceinline__ Lay layout(const DevParams& P, const Args& A, char* lds)
+    {
+        Lay L;
+        L.wf = win_floats(P.W);
+        L.win = reinterpret_cast<float*>(lds);
+        L.hint = reinterpret_cast<int*>(L.win + 4 * L.wf);
+        L.dimg = reinterpret_cast<float*>(lds + front_bytes(P.W) + (sizeof(LocompLds<R>) + 15) / 16 * 16);
+        L.wts = L.dimg + (size_t)A.G * S4C * 256;
+        return L;
+    }
+    static __device__ __forceinline__ LocompLds<R>& group(const DevParams& P, const Args&, char* lds)
+    {
+        return *reinterpret_cast<LocompLds<R>*>(lds + front_bytes(P.W));
+    }
+    static constexpr bool kOwnInit = true;      // the loop kernel computes the initial correlation itself (no launch in front of it)
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds, int b, Sync&)
+    {
+        const Lay L = layout(P, A, lds);
+        lds_copy16(L.dimg, A.dimg, A.G * S4C * 256 * (int)sizeof(float));
+        for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) L.wts[i] = (HAS_W && i < P.K) ? S.weights[i] : 0.0f;
+        __syncthreads();
+        // a fresh batch (no round yet): the initial correlation (:1293 convolve1d 'same': ZERO padded), 4W-1 rows at a time
+        if (S.stats[(int64_t)b * ST_COUNT + ST_ROUNDS] == 0 && S.stats[(int64_t)b * ST_COUNT + ST_EVENTS] == 0) {
+            Sig<R> G{};
+            G.r = S.residual + (int64_t)b * P.T; G.bc = S.best_c + (int64_t)b * P.T; G.bk = S.best_k + (int64_t)b * P.T;
+            const int step = 4 * P.W - 1;
+            for (int t0 = 0; t0 < P.T; t0 += step) {
+                rows(P, G, A, lds, t0, min(step, P.T - t0), false, 0, -1);
+                __syncthreads();
+            }
+        }
+    }
+    // rows [t0, t0 + nrows) from the residual window that starts at sample t0 - off: (coefficient, atom) of every row inside the
+    // signal.  Samples outside it: none when `interior`; else reflected about the slice [sidx, sidx + nslice) (np.pad 'reflect',
+    // :1046), or zero (nslice < 0: the initial correlation, :159-164)
+    static __device__ __forceinline__ void rows(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int t0, int nrows,
+                                                bool interior, int sidx, int nslice)
+    {
+        const Lay L = layout(P, A, lds);
+        const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int span = nrows + W - 1, wstart = t0 - P.off;
+        for (int i = tid; i < L.wf + 3; i += kThreads) {
+            float v = 0.0f;
+            if (i < span) {
+                const int gi = wstart + i;
+                if (interior) v = G.r[gi];
+                else if (nslice < 0) v = (gi >= 0 && gi < T) ? G.r[gi] : 0.0f;
+                else v = G.r[reflect_index(gi, sidx, nslice)];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (i - c >= 0 && i - c < L.wf) L.win[c * L.wf + i - c] = v;   // copy c: win_c[j] = win[j + c]
+        }
+        __syncthreads();
+        const int nt = (nrows + TP - 1) / TP;
+        for (int q = wv; q < nt; q += kWaves) {
+            int grp;
+            (void)mfma_tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4C, lane, grp);
+            if (lane < TP) L.hint[TP * q + lane] = grp;
+        }
+        __syncthreads();
+        // two rows per wave and pass (one per half-wave): lane l & 31 runs the chain of atom 32 g + (l & 31) of the row's group
+        const int half = lane >> 5, l5 = lane & 31;
+        for (int pr = wv; 2 * pr < nrows; pr += kWaves) {
+            const int row = 2 * pr + half;
+            const int rq = row < nrows ? row : nrows - 1;
+            const int t = t0 + rq;
+            const int k = 32 * L.hint[rq] + l5;
+            float bc = 0.0f;
+            int sb = __float_as_int(-1.0f);
+            if (k < P.K) {
+                bc = resolve_chain<S4C>(L.dimg, L.win + (rq & 3) * L.wf + (rq & ~3), k, S4C);
+                float sc;
+                if (HAS_W) { const float sw = bc * L.wts[k]; sc = fabsf(sw); } else sc = fabsf(bc);
+                sb = __float_as_int(sc);                       // (scores are >= 0: their bit patterns order like the values)
+            }
+            int m = sb;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+            int idx = sb == m ? k : INT_MAX;                   // the lowest atom among equals (np.argmax)
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) idx = min(idx, __shfl_xor(idx, d));
+            const float c = __shfl(bc, (lane & 32) | (idx & 31));
+            if (l5 == 0 && row < nrows && t >= 0 && t < T) { G.bc[t] = c; G.bk[t] = idx; }      // overlapReplace clipping (utils.py:133-161)
+        }
+    }
+    // rows p-(W-1) .. p+(W-1) around one atom (:1018-1051)
+    template <typename SH>
+    static __device__ __forceinline__ void run(const DevParams& P, const State<R>&, const Sig<R>& G, SH&, const Args& A, char* lds, int p, int)
+    {
+        const int T = P.T, W = P.W;
+        const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);          // :1028-1038
+        const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend;
+        rows(P, G, A, lds, p - (W - 1), 2 * W - 1, tstart >= 0 && tend <= T - 1, sidx, eidx - sidx + 1);
+    }
+    // the rows of a group of atoms between pmin and pmax, none of which reaches a signal end: a row's value only depends on the
+    // final residual, so the union of their row ranges is computed once
+    static __device__ __forceinline__ void run_span(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax)
+    {
+        rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0);
     }
 };
 
@@ -202,23 +359,76 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     }
 
     // ---- :1336-1341 / :1345-1350 coefficients += fitted; residual -= fitted * atom, with the local energies (:996-1016)
+    auto book = [&](int gi, int tp, int kk, R cf) {                      // (one thread)
+        int si = L.si[gi];
+        double before = 0.0;
+        if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }
+        else before = G.slot_a[si];
+        const double after = before + (double)cf;
+        G.slot_a[si] = after;
+        if (gi == 0) {
+            if (before != 0.0) sh.ndup += 1;
+            const int ev = sh.nev++;
+            G.ev_t[ev] = tp; G.ev_k[ev] = kk; G.ev_c[ev] = c;
+        }
+        sh.nnz += (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
+    };
+    // Short atoms (a few elements per lane): the whole group by ONE wave, atom after atom, without a workgroup barrier per
+    // atom.  Lane l carries the four strided partial sums l, 64+l, 128+l, 192+l of the workgroup form (wave_window_energy):
+    // the same trees, the same bits.
+    const bool wave_apply = Pol::kWaveApply && W * F <= 1024;            // uniform
+    if (wave_apply) {
+        if (wv == 0)
+            for (int gi = 0; gi < n; ++gi) {
+                const int tp = L.t[gi], kk = L.k[gi];
+                const R cf = L.a[gi];
+                if (lane == 0) book(gi, tp, kk, cf);
+                int s, e, es;
+                const int cnt = centered_span(T, W, tp, s, e, es) * F;
+                const R nc = -cf;
+                const R* dk = S.D + ((int64_t)kk * W + es) * F;
+                R* rv = G.r + (int64_t)s * F;
+                R b4[4] = {(R)0, (R)0, (R)0, (R)0}, a4[4] = {(R)0, (R)0, (R)0, (R)0};
+                for (int i0 = lane; i0 < cnt; i0 += kThreads) {
+                    R v[4], d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = (R)0; d[u] = (R)0; if (i < cnt) { v[u] = rv[i]; d[u] = dk[i]; } }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < cnt) {
+                            const R sq = v[u] * v[u];
+                            b4[u] = b4[u] + sq;
+                            const R prod = nc * d[u];            // -c*D[k] rounded, then += (utils.py:120,129)
+                            const R vn = v[u] + prod;
+                            rv[i] = vn;
+                            const R sq2 = vn * vn;
+                            a4[u] = a4[u] + sq2;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const R ob = __shfl_down(b4[u], m), oa = __shfl_down(a4[u], m);
+                        b4[u] = b4[u] + ob; a4[u] = a4[u] + oa;
+                    }
+                }
+                if (lane == 0) {
+                    const R b01 = b4[0] + b4[1], b23 = b4[2] + b4[3], a01 = a4[0] + a4[1], a23 = a4[2] + a4[3];
+                    const R pb = b01 + b23, pa = a01 + a23;
+                    const R l = pb - pa;
+                    L.loss = L.loss + l;                         // :1005 summed over the group
+                }
+                __threadfence_block();                           // this atom's residual stores before the next atom's loads
+            }
+        sy.full();
+    } else
     for (int gi = 0; gi < n; ++gi) {
         const int tp = L.t[gi], kk = L.k[gi];
         const R cf = L.a[gi];
-        if (tid == 0) {
-            int si = L.si[gi];
-            double before = 0.0;
-            if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }
-            else before = G.slot_a[si];
-            const double after = before + (double)cf;
-            G.slot_a[si] = after;
-            if (gi == 0) {
-                if (before != 0.0) sh.ndup += 1;
-                const int ev = sh.nev++;
-                G.ev_t[ev] = tp; G.ev_k[ev] = kk; G.ev_c[ev] = c;
-            }
-            sh.nnz += (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
-        }
+        if (tid == 0) book(gi, tp, kk, cf);
         int s, e, es;
         const int len = centered_span(T, W, tp, s, e, es);
         R pb = (R)0, pa = (R)0;
@@ -268,6 +478,18 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     // ---- :1353 re-correlation around every atom of the group (from the final residual), then the maxima of their segments
     Pol::before_runs(A, plds);
     sy.full();
+    bool joint = Pol::kUnionRows && n > 1;
+    int pmin = p, pmax = p;
+    if (joint)
+        for (int gi = 0; gi < n; ++gi) {                               // uniform
+            const int tp = L.t[gi];
+            joint = joint && tp - P.off - (W - 1) >= 0 && tp + W / 2 + (W - 1) <= T - 1;      // interior: no padding in its rows (:1028-1046)
+            pmin = min(pmin, tp); pmax = max(pmax, tp);
+        }
+    if (joint && pmax - pmin <= 2 * W) {
+        Pol::run_span(P, G, A, plds, pmin, pmax);
+        sy.full();
+    } else
     for (int gi = 0; gi < n; ++gi) {
         Pol::run(P, S, G, sh, A, plds, L.t[gi], L.k[gi]);
         sy.full();

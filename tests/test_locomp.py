@@ -122,6 +122,8 @@ BATCH_CASES = [
     (600, 10, 9, 12, np.float64, 40, dict(toleranceSnr=25.0, nbBlocks=4), True),
     (600, 10, 9, 12, np.float64, 40, dict(nbNonzeroCoefs=30), True),
     (500, 8, 17, 1, np.float32, 25, dict(toleranceSnr=15.0, nbBlocks=2, weights='w'), False),
+    (2000, 70, 64, 1, np.float32, 40, dict(toleranceSnr=20.0, nbBlocks=5, weights='w'), False),
+    (1500, 33, 32, 1, np.float32, 40, dict(toleranceSnr=20.0), False),
 ]
 
 
@@ -146,6 +148,17 @@ def test_locomp_device_loop_vs_host_loop(case, monkeypatch):
     reasons = res.stop_reasons()
     assert reasons.count('group') <= 1                         # (a noisy multi-feature member may outgrow the kernel's group: host loop)
     again = dev.computeCoefficientsBatch(xs, D, **kw)
+    if 'mfma' in res.variant:
+        # single-feature float32: the re-correlations ran on the matrix cores; the dense form gives the same bits
+        assert F == 1 and dtype == np.float32
+        monkeypatch.setenv('HSCMP_LOCOMP_NO_MFMA', '1')
+        dense = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+        monkeypatch.delenv('HSCMP_LOCOMP_NO_MFMA')
+        assert 'mfma' not in dense.variant and np.array_equal(dense.stats, res.stats)
+        for b in range(xs.shape[0]):
+            assert (res.coefficients[b] != dense.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], dense.residuals[b])
+    else:
+        assert not (F == 1 and dtype == np.float32 and (W + 7) // 8 in (2, 4, 8))
     monkeypatch.setenv('HSCMP_LOCOMP_HOST', '1')
     tol = 2e-5 if dtype == np.float32 else 1e-9
     for b in range(xs.shape[0]):
