@@ -608,22 +608,30 @@ template <typename R> static int launch_iterate_locomp(hscmp_ctx* ctx, const Dev
     return HSCMP_OK;
 }
 
-// single-feature float32 with a dictionary image (hscmp_set_dictionary built it): the re-correlations on the matrix cores
-template <int S4C, bool HAS_W> static int launch_iterate_locomp_mfma_t(hscmp_ctx* ctx, const DevParams& P0, bool dry)
+// single-feature float32 with a dictionary image (hscmp_set_dictionary built it): the re-correlations on the matrix cores.
+// Two signals per workgroup (one image per CU, two signals on its matrix pipe) when the batch has more signals than the chip has CUs.
+template <int S4C, bool HAS_W, int GS> static int launch_iterate_locomp_mfma_g(hscmp_ctx* ctx, const DevParams& P0, bool dry)
 {
-    using Pol = LocompMfma<S4C, HAS_W>;
+    using Pol = LocompMfma<S4C, HAS_W, GS>;
     State<float> S = make_state<float>(ctx);
     DevParams P = P0;
     set_segments(P, Pol::kMaxSegments);
     MfmaArgs A;
     A.dimg = (const float*)ctx->d_Dfrag; A.G = mfma_groups(P.K); A.S4 = S4C; A.has_w = HAS_W ? 1 : 0;
-    const size_t lds = ((sizeof(typename Pol::Shared) + 15) / 16) * 16 + Pol::extra_lds_bytes(P, A);
+    const size_t lds = Pol::total_lds_bytes(P, A);
     if (lds > (size_t)158 * 1024) return -1;
     if (dry) return 0;
     auto kern = iterate_kernel<float, Pol>;
     HIP_TRY(ctx, set_dyn_lds((const void*)kern, lds));
-    hipLaunchKernelGGL(kern, dim3(P.B), dim3(kThreads), lds, ctx->stream, P, S, A);
+    hipLaunchKernelGGL(kern, dim3((P.B + GS - 1) / GS), dim3(GS * kThreads), lds, ctx->stream, P, S, A);
     return HSCMP_OK;
+}
+template <int S4C, bool HAS_W> static int launch_iterate_locomp_mfma_t(hscmp_ctx* ctx, const DevParams& P, bool dry)
+{
+    const char* e = getenv("HSCMP_LOCOMP_PAIR");
+    const bool pair = e ? atoi(e) != 0 : P.B > mfma_device_cus();
+    if (pair && launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, dry);
+    return launch_iterate_locomp_mfma_g<S4C, HAS_W, 1>(ctx, P, dry);
 }
 static int launch_iterate_locomp_mfma(hscmp_ctx* ctx, const DevParams& P, bool dry)
 {

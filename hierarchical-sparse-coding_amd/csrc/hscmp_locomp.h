@@ -38,7 +38,9 @@ template <typename R> struct LocompLds {
     R loss, last_e;                   // energyLoss of the group (:998-1014), lastEnergyResidual (:1316)
     double b[kLocompMax];             // right-hand side <d_i, r>, then the solution
     double diag[kLocompMax];          // original diagonal (rank test)
-    double g[kLocompMax * kLocompMax];    // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor (lower)
+    double g[kLocompMax * (kLocompMax + 1) / 2];      // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor: lower
+                                                       // triangle, row i at i (i + 1) / 2
+    static __device__ __forceinline__ int at(int i, int j) { return i * (i + 1) / 2 + j; }       // (j <= i)
 };
 
 // the dense table-free loop (GenericRecorr) with the group re-fit as its atom body
@@ -47,9 +49,13 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kWaveApply = true;            // (no per-policy residual update: short atoms go through one wave)
     static constexpr bool kUnionRows = false;
     static constexpr bool kOwnInit = false;
-    static __device__ __forceinline__ void run_span(const DevParams&, const Sig<R>&, const typename GenericRecorr<R>::Args&, char*, int, int) {}
     using Base = GenericRecorr<R>;
     using Args = typename Base::Args;
+    template <typename SH, typename SY>
+    static __device__ __forceinline__ void lrun(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const Args& A, char* lds, int p, int k, SY&)
+    { Base::run(P, S, G, sh, A, lds, p, k); }
+    template <typename SY>
+    static __device__ __forceinline__ void lrun_span(const DevParams&, const Sig<R>&, const Args&, char*, int, int, SY&) {}
     static size_t extra_lds_bytes(const DevParams& P) { return Base::extra_lds_bytes(P) + sizeof(LocompLds<R>) + 16; }
     static __device__ __forceinline__ LocompLds<R>& group(const DevParams&, const Args&, char* lds)
     {
@@ -64,9 +70,13 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = false;
-    static __device__ __forceinline__ void run_span(const DevParams&, const Sig<R>&, const SparseArgs<R>&, char*, int, int) {}
     using Base = SparseRecorr<R, false>;
     using Args = typename Base::Args;
+    template <typename SH, typename SY>
+    static __device__ __forceinline__ void lrun(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const Args& A, char* lds, int p, int k, SY&)
+    { Base::run(P, S, G, sh, A, lds, p, k); }
+    template <typename SY>
+    static __device__ __forceinline__ void lrun_span(const DevParams&, const Sig<R>&, const Args&, char*, int, int, SY&) {}
     static size_t policy_bytes(const DevParams& P, const Args& A) { return ((Base::extra_lds_bytes(P, A) + 15) / 16) * 16; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return policy_bytes(P, A) + sizeof(LocompLds<R>) + 16; }
     static __device__ __forceinline__ LocompLds<R>& group(const DevParams& P, const Args& A, char* lds)
@@ -86,24 +96,28 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
 // (coefficient, atom) per position like the dense form, so a tile's result -- the row's best SCORE and the 32-atom group that holds the
 // first atom attaining it (mfma_tile_score) -- is resolved right away: one chain per lane over that group's atoms (the pinned
 // sequential chain, as the dense form computes it), arg-max with the lowest atom among equals.
-// LDS behind the control block: [window | group hints | per-wave resolve windows][LocompLds][dictionary image | weights]
-template <int S4C, bool HAS_W> struct LocompMfma {
+// GS signals per workgroup (1 or 2) share ONE dictionary image: with two, a CU holds two signals and the matrix pipe has the other
+// signal's tiles to run while one is in its serial steps (the 64 KB image and the per-signal state leave no room for two workgroups).
+// LDS: [dictionary image | weights] then per signal [control block][window x 4 | group hints][LocompLds]
+template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     using R = float;
-    static constexpr int kMaxSegments = kMaxSeg;
+    static constexpr int kMaxSegments = GS == 1 ? kMaxSeg : kMfmaMaxSeg;
     static constexpr bool kFused = false;
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
-    static constexpr int kMinWavesPerSimd = 1;
+    static constexpr int kMinWavesPerSimd = GS;
     static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = false;
-    static constexpr int kGroup = 1;
+    static constexpr int kGroup = GS;
     static constexpr int TP = 32;
-    using Shared = IterSharedT<float, kMaxSeg>;
+    using Shared = IterSharedT<float, kMaxSegments>;
     using Args = MfmaArgs;
-    using Sync = HwSync;
-    static __device__ __forceinline__ Sync make_sync(Shared&) { return Sync(); }
-    static __device__ __forceinline__ void prologue_shared(const DevParams&, const State<R>&, const Args&, char*) {}
-    static __device__ __forceinline__ int signal_lds_offset(const DevParams&, const Args&) { return 0; }
+    using Sync = typename std::conditional<GS == 1, HwSync, SoftSync>::type;
+    static __device__ __forceinline__ Sync make_sync(Shared& sh)
+    {
+        if constexpr (GS == 1) return HwSync();
+        else { SoftSync sy; sy.init(&sh.bar, &sh.bar_cnt); return sy; }
+    }
     static __device__ __forceinline__ void epilogue(const DevParams&, const State<R>&, const Args&, char*, int) {}
     static __device__ __forceinline__ void resolve_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, int&, R&) {}
     static __device__ __forceinline__ const R* weights(const DevParams&, const State<R>& S, const Args&, char*) { return S.weights; }
@@ -126,8 +140,14 @@ template <int S4C, bool HAS_W> struct LocompMfma {
         // four copies of the window, copy c shifted by c samples: row r's window starts 16-byte aligned in copy r & 3
         return ((4 * (size_t)win_floats(W) + (size_t)max_tiles(W) * TP) * sizeof(float) + 15) / 16 * 16;
     }
-    static __host__ __device__ size_t image_bytes(const Args& A) { return ((size_t)A.G * S4C * 256 + 32 * (size_t)A.G) * sizeof(float); }
-    static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return front_bytes(P.W) + (sizeof(LocompLds<R>) + 15) / 16 * 16 + image_bytes(A); }
+    static __host__ __device__ size_t image_bytes(const Args& A) { return ((size_t)A.G * S4C * 256 + 32 * (size_t)A.G) * sizeof(float); }     // (x 16)
+    static __host__ __device__ size_t policy_bytes(int W) { return front_bytes(W) + (sizeof(LocompLds<R>) + 15) / 16 * 16; }
+    static __host__ __device__ size_t per_signal_bytes(int W) { return ((sizeof(Shared) + 15) / 16) * 16 + policy_bytes(W); }
+    static size_t total_lds_bytes(const DevParams& P, const Args& A) { return image_bytes(A) + (size_t)GS * per_signal_bytes(P.W); }
+    static __device__ __forceinline__ int signal_lds_offset(const DevParams& P, const Args& A)
+    {
+        return __builtin_amdgcn_readfirstlane((int)image_bytes(A) + (GS == 1 ? 0 : gsig() * (int)per_signal_bytes(P.W)));
+    }
     struct Lay { float* win; int* hint; float* dimg; float* wts; int wf; };
     static __device__ __forceinline__ Lay layout(const DevParams& P, const Args& A, char* lds)
     {
@@ -135,7 +155,7 @@ template <int S4C, bool HAS_W> struct LocompMfma {
         L.wf = win_floats(P.W);
         L.win = reinterpret_cast<float*>(lds);
         L.hint = reinterpret_cast<int*>(L.win + 4 * L.wf);
-        L.dimg = reinterpret_cast<float*>(lds + front_bytes(P.W) + (sizeof(LocompLds<R>) + 15) / 16 * 16);
+        L.dimg = reinterpret_cast<float*>(dyn_lds());
         L.wts = L.dimg + (size_t)A.G * S4C * 256;
         return L;
     }
@@ -143,21 +163,30 @@ template <int S4C, bool HAS_W> struct LocompMfma {
     {
         return *reinterpret_cast<LocompLds<R>*>(lds + front_bytes(P.W));
     }
-    static constexpr bool kOwnInit = true;      // the loop kernel computes the initial correlation itself (no launch in front of it)
-    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds, int b, Sync&)
+    // the dictionary image and the weights, once per workgroup (all its threads, hardware barrier)
+    static __device__ __forceinline__ void prologue_shared(const DevParams& P, const State<R>& S, const Args& A, char* smem)
     {
-        const Lay L = layout(P, A, lds);
-        lds_copy16(L.dimg, A.dimg, A.G * S4C * 256 * (int)sizeof(float));
-        for (int i = threadIdx.x; i < 32 * A.G; i += kThreads) L.wts[i] = (HAS_W && i < P.K) ? S.weights[i] : 0.0f;
+        float* dimg = reinterpret_cast<float*>(smem);
+        float* wts = dimg + (size_t)A.G * S4C * 256;
+        lds_copy16(dimg, A.dimg, A.G * S4C * 256 * (int)sizeof(float), (int)threadIdx.x, GS * kThreads);
+        for (int i = threadIdx.x; i < 32 * A.G; i += GS * kThreads) wts[i] = (HAS_W && i < P.K) ? S.weights[i] : 0.0f;
+        if (GS > 1 && ltid() == 0) {                          // the counter the signal's four waves meet at (SoftSync)
+            Shared* sh = reinterpret_cast<Shared*>(smem + signal_lds_offset(P, A));
+            sh->bar = 0u; sh->bar_cnt = 0;
+        }
         __syncthreads();
+    }
+    static constexpr bool kOwnInit = true;      // the loop kernel computes the initial correlation itself (no launch in front of it)
+    static __device__ __forceinline__ void prologue(const DevParams& P, const State<R>& S, const Args& A, char* lds, int b, Sync& sy)
+    {
         // a fresh batch (no round yet): the initial correlation (:1293 convolve1d 'same': ZERO padded), 4W-1 rows at a time
         if (S.stats[(int64_t)b * ST_COUNT + ST_ROUNDS] == 0 && S.stats[(int64_t)b * ST_COUNT + ST_EVENTS] == 0) {
             Sig<R> G{};
             G.r = S.residual + (int64_t)b * P.T; G.bc = S.best_c + (int64_t)b * P.T; G.bk = S.best_k + (int64_t)b * P.T;
             const int step = 4 * P.W - 1;
             for (int t0 = 0; t0 < P.T; t0 += step) {
-                rows(P, G, A, lds, t0, min(step, P.T - t0), false, 0, -1);
-                __syncthreads();
+                rows(P, G, A, lds, t0, min(step, P.T - t0), false, 0, -1, sy);
+                sy.full();
             }
         }
     }
@@ -165,10 +194,10 @@ template <int S4C, bool HAS_W> struct LocompMfma {
     // signal.  Samples outside it: none when `interior`; else reflected about the slice [sidx, sidx + nslice) (np.pad 'reflect',
     // :1046), or zero (nslice < 0: the initial correlation, :159-164)
     static __device__ __forceinline__ void rows(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int t0, int nrows,
-                                                bool interior, int sidx, int nslice)
+                                                bool interior, int sidx, int nslice, Sync& sy)
     {
         const Lay L = layout(P, A, lds);
-        const int T = P.T, W = P.W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = tid >> 6;
         const int span = nrows + W - 1, wstart = t0 - P.off;
         for (int i = tid; i < L.wf + 3; i += kThreads) {
             float v = 0.0f;
@@ -181,14 +210,14 @@ template <int S4C, bool HAS_W> struct LocompMfma {
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (i - c >= 0 && i - c < L.wf) L.win[c * L.wf + i - c] = v;   // copy c: win_c[j] = win[j + c]
         }
-        __syncthreads();
+        sy.lds();
         const int nt = (nrows + TP - 1) / TP;
         for (int q = wv; q < nt; q += kWaves) {
             int grp;
             (void)mfma_tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4C, lane, grp);
             if (lane < TP) L.hint[TP * q + lane] = grp;
         }
-        __syncthreads();
+        sy.lds();
         // two rows per wave and pass (one per half-wave): lane l & 31 runs the chain of atom 32 g + (l & 31) of the row's group
         const int half = lane >> 5, l5 = lane & 31;
         for (int pr = wv; 2 * pr < nrows; pr += kWaves) {
@@ -216,19 +245,22 @@ template <int S4C, bool HAS_W> struct LocompMfma {
     }
     // rows p-(W-1) .. p+(W-1) around one atom (:1018-1051)
     template <typename SH>
-    static __device__ __forceinline__ void run(const DevParams& P, const State<R>&, const Sig<R>& G, SH&, const Args& A, char* lds, int p, int)
+    static __device__ __forceinline__ void lrun(const DevParams& P, const State<R>&, const Sig<R>& G, SH&, const Args& A, char* lds, int p, int, Sync& sy)
     {
         const int T = P.T, W = P.W;
         const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);          // :1028-1038
         const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend;
-        rows(P, G, A, lds, p - (W - 1), 2 * W - 1, tstart >= 0 && tend <= T - 1, sidx, eidx - sidx + 1);
+        rows(P, G, A, lds, p - (W - 1), 2 * W - 1, tstart >= 0 && tend <= T - 1, sidx, eidx - sidx + 1, sy);
     }
     // the rows of a group of atoms between pmin and pmax, none of which reaches a signal end: a row's value only depends on the
     // final residual, so the union of their row ranges is computed once
-    static __device__ __forceinline__ void run_span(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax)
+    static __device__ __forceinline__ void lrun_span(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax, Sync& sy)
     {
-        rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0);
+        rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0, sy);
     }
+    // (the step-by-step atom body of the greedy loop is never instantiated for a kLocomp policy, but must compile)
+    template <typename SH>
+    static __device__ __forceinline__ void run(const DevParams&, const State<R>&, const Sig<R>&, SH&, const Args&, char*, int, int) {}
 };
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -313,7 +345,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     for (int x = lane; x < (hi - lo) * F; x += 64) acc += (double)di[x] * (double)dj[x];
                     acc = wave_sum_f64(acc);
                 }
-                if (lane == 0) { L.g[i * kLocompMax + j] = acc; if (i == j) L.diag[i] = acc; }
+                if (lane == 0) { L.g[L.at(i, j)] = acc; if (i == j) L.diag[i] = acc; }
             }
         }
         sy.full();
@@ -321,19 +353,19 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         // marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
         if (wv == 0) {
             for (int j = 0; j < n; ++j) {
-                const double piv = L.g[j * kLocompMax + j];
+                const double piv = L.g[L.at(j, j)];
                 const bool dead = !(piv > kLocompDead * L.diag[j]);            // uniform
                 const double ljj = dead ? 0.0 : sqrt(piv);
-                if (lane == 0) L.g[j * kLocompMax + j] = ljj;
+                if (lane == 0) L.g[L.at(j, j)] = ljj;
                 if (lane > j && lane < n) {
-                    const double lij = dead ? 0.0 : L.g[lane * kLocompMax + j] / ljj;
-                    L.g[lane * kLocompMax + j] = lij;
+                    const double lij = dead ? 0.0 : L.g[L.at(lane, j)] / ljj;
+                    L.g[L.at(lane, j)] = lij;
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane > j && lane < n) {
-                    const double lij = L.g[lane * kLocompMax + j];
-                    for (int q = j + 1; q <= lane; ++q) L.g[lane * kLocompMax + q] -= lij * L.g[q * kLocompMax + j];
+                    const double lij = L.g[L.at(lane, j)];
+                    for (int q = j + 1; q <= lane; ++q) L.g[L.at(lane, q)] -= lij * L.g[L.at(q, j)];
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -342,14 +374,14 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                 // forward (L y = b), then backward (L^T x = y); a dead atom keeps 0
                 for (int i = 0; i < n; ++i) {
                     double v = L.b[i];
-                    for (int q = 0; q < i; ++q) v -= L.g[i * kLocompMax + q] * L.b[q];
-                    const double d = L.g[i * kLocompMax + i];
+                    for (int q = 0; q < i; ++q) v -= L.g[L.at(i, q)] * L.b[q];
+                    const double d = L.g[L.at(i, i)];
                     L.b[i] = d > 0.0 ? v / d : 0.0;
                 }
                 for (int i = n - 1; i >= 0; --i) {
                     double v = L.b[i];
-                    for (int q = i + 1; q < n; ++q) v -= L.g[q * kLocompMax + i] * L.b[q];
-                    const double d = L.g[i * kLocompMax + i];
+                    for (int q = i + 1; q < n; ++q) v -= L.g[L.at(q, i)] * L.b[q];
+                    const double d = L.g[L.at(i, i)];
                     L.b[i] = d > 0.0 ? v / d : 0.0;
                 }
                 for (int i = 0; i < n; ++i) L.a[i] = (R)L.b[i];
@@ -487,11 +519,11 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             pmin = min(pmin, tp); pmax = max(pmax, tp);
         }
     if (joint && pmax - pmin <= 2 * W) {
-        Pol::run_span(P, G, A, plds, pmin, pmax);
+        Pol::lrun_span(P, G, A, plds, pmin, pmax, sy);
         sy.full();
     } else
     for (int gi = 0; gi < n; ++gi) {
-        Pol::run(P, S, G, sh, A, plds, L.t[gi], L.k[gi]);
+        Pol::lrun(P, S, G, sh, A, plds, L.t[gi], L.k[gi], sy);
         sy.full();
     }
     for (int gi = 0; gi < n; ++gi) {

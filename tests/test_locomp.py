@@ -155,8 +155,14 @@ def test_locomp_device_loop_vs_host_loop(case, monkeypatch):
         dense = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
         monkeypatch.delenv('HSCMP_LOCOMP_NO_MFMA')
         assert 'mfma' not in dense.variant and np.array_equal(dense.stats, res.stats)
+        # ... and so do two signals per workgroup around one dictionary image (what a batch larger than the chip runs)
+        monkeypatch.setenv('HSCMP_LOCOMP_PAIR', '1')
+        pair = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+        monkeypatch.delenv('HSCMP_LOCOMP_PAIR')
+        assert np.array_equal(pair.stats, res.stats)
         for b in range(xs.shape[0]):
             assert (res.coefficients[b] != dense.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], dense.residuals[b])
+            assert (res.coefficients[b] != pair.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], pair.residuals[b])
     else:
         assert not (F == 1 and dtype == np.float32 and (W + 7) // 8 in (2, 4, 8))
     monkeypatch.setenv('HSCMP_LOCOMP_HOST', '1')
