@@ -381,13 +381,16 @@ def run_secondary(args, ctx):
     import bench_hsc
     sec = {}
     t_begin = time.perf_counter()
-    for name, config, taps in (('config4_17taps', 4, 17), ('config4_16taps', 4, 16), ('config5', 5, 17)):
+    # (config 4 also with the method the reference's own script runs it with -- learn_mlcsc_dataset.py:108 builds the encoder with
+    #  its default, LoCOMP: the device loop of csrc/hscmp_locomp.h)
+    for name, config, taps, method in (('config4_17taps', 4, 17, 'cmp'), ('config4_16taps', 4, 16, 'cmp'), ('config5', 5, 17, 'cmp'),
+                                       ('config4_17taps_locomp', 4, 17, 'locomp')):
         if time.perf_counter() - t_begin > args.secondary_budget_s:
             sec[name] = {'skipped': 'time budget of the secondary section (%d s) spent' % args.secondary_budget_s}
             continue
         a = copy.copy(args)
-        a.config, a.level1_taps, a.batch, a.T = config, taps, 0, 65536
-        a.steps, a.warmup, a.no_cpu_baseline = 3, 1, True
+        a.config, a.level1_taps, a.batch, a.T, a.method = config, taps, 0, 65536, method
+        a.steps, a.warmup, a.no_cpu_baseline = (3 if method == 'cmp' else 2), 1, True
         t0 = time.perf_counter()
         try:
             sec[name] = bench_hsc.compact(bench_hsc.run(a, ctx))

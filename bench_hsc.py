@@ -265,6 +265,7 @@ def compact(out):
         return None
     keep = {k: out[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'value_incl_residual_transfer')}
     keep['workload'] = out['config']['workload']
+    keep['method'] = out['config'].get('method', 'cmp')
     keep['signals_per_gpu'] = out['config']['signals_per_gpu']
     keep['selections_per_step'] = out['config']['selections_per_step']
     keep['kernel_ms_per_step'] = out['config']['kernel_ms_per_step']

@@ -128,6 +128,40 @@ def test_overflowing_residual_ends_without_a_wild_index(shape, blocks, rp, monke
     assert len(t) > 0 and t.min() >= 0 and t.max() < T and k.min() >= 0 and k.max() < D.shape[0]
 
 
+@pytest.mark.parametrize('shape,blocks', OVERFLOW_CASES)
+def test_overflowing_residual_in_the_locomp_loop(shape, blocks):
+    """The same inputs through the LoCOMP loop (dense, sparse and matrix-core policies): NaN Gram entries, pivots and
+    scores must still leave valid positions, atoms and slots -- the run ends with a stop reason or 'does not converge'."""
+    import logging
+    from hsc_amd.modeling import LoCOMP
+    from hsc_amd._native import HscmpError
+    rs = np.random.RandomState(5)
+    T, F, K, W = shape[:4]
+    if len(shape) > 4:
+        D = np.zeros((K, W, F), dtype=np.float32)
+        for k in range(K):
+            for _ in range(3):
+                D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5)
+    else:
+        D = rs.standard_normal((K, W, F)).astype(np.float32)
+    D /= np.sqrt(np.sum(np.square(D), axis=(1, 2), keepdims=True))
+    x = (rs.standard_normal((T, F)) * 1e38).astype(np.float32)
+    if F == 1:
+        x, D = x[:, 0], D[:, :, 0]
+    coder = LoCOMP()
+    logging.disable(logging.WARNING)
+    try:
+        with np.errstate(all='ignore'):
+            res = coder.computeCoefficientsBatch(x[np.newaxis], D, nbNonzeroCoefs=50, nbBlocks=blocks, minCoefficients=None)
+    except HscmpError as ex:
+        assert 'does not converge' in str(ex)
+        return
+    finally:
+        logging.disable(logging.NOTSET)
+    t, k, c = res.events[0]
+    assert 'locomp' in res.variant and len(t) > 0 and t.min() >= 0 and t.max() < T and k.min() >= 0 and k.max() < D.shape[0]
+
+
 def test_long_signals():
     """A million samples on the MFMA path (segment maxima at their largest segment size), and a multi-feature input
     longer than the row-bitmap / sparse-initial-correlation limit (262144 rows): generic initial correlation, sparse loop."""
