@@ -628,9 +628,13 @@ template <int S4C, bool HAS_W, int GS> static int launch_iterate_locomp_mfma_g(h
 }
 template <int S4C, bool HAS_W> static int launch_iterate_locomp_mfma_t(hscmp_ctx* ctx, const DevParams& P, bool dry)
 {
-    const char* e = getenv("HSCMP_LOCOMP_PAIR");
-    const bool pair = e ? atoi(e) != 0 : P.B > mfma_device_cus();
-    if (pair && launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, dry);
+    // signals per workgroup: two when the batch has more signals than the chip has CUs.  (HSCMP_LOCOMP_PACK = 1 / 2 / 4 overrides.  Four
+    // per workgroup leave each signal a group capacity of 32 atoms: at BASELINE config 4 -- 2000 coefficients per signal, the
+    // largest neighbourhoods 30-56 atoms -- most signals would outgrow it and fall back to the host loop; not chosen automatically.)
+    const char* e = getenv("HSCMP_LOCOMP_PACK");
+    const int pack = e ? atoi(e) : P.B > mfma_device_cus() ? 2 : 1;
+    if (pack >= 4 && launch_iterate_locomp_mfma_g<S4C, HAS_W, 4>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 4>(ctx, P, dry);
+    if (pack >= 2 && launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, dry);
     return launch_iterate_locomp_mfma_g<S4C, HAS_W, 1>(ctx, P, dry);
 }
 static int launch_iterate_locomp_mfma(hscmp_ctx* ctx, const DevParams& P, bool dry)

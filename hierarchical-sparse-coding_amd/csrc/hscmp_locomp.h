@@ -22,7 +22,8 @@
 
 namespace hscmp {
 
-constexpr int kLocompMax = 64;        // atoms of a group, the selected one included (larger: STOP_GROUP, the host loop takes over)
+constexpr int kLocompMax = 64;        // atoms of a group, the selected one included (larger: STOP_GROUP, the host loop takes over); a policy
+                                      // that packs several signals into a workgroup may take fewer (Pol::kMaxGroup)
 // Nearly dependent atoms in a group (a Cholesky pivot that all but vanishes against its diagonal entry): the re-fit is solved in
 // float64 whatever the dictionary's dtype, an atom the others already span keeps coefficient 0.  The reference's pseudo-inverse is
 // an SVD in the DICTIONARY's dtype with a cut-off of 1e-15: on such a group its float32 result is round-off amplified by the
@@ -30,15 +31,15 @@ constexpr int kLocompMax = 64;        // atoms of a group, the selected one incl
 // coefficient (the hierarchical per-signal entry therefore keeps the reference's own LAPACK call on the host).
 constexpr double kLocompDead = 1e-12;
 
-template <typename R> struct LocompLds {
+template <typename R, int NMAX = kLocompMax> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
-    int t[kLocompMax], k[kLocompMax], si[kLocompMax];       // position, atom, coefficient slot (-1: none yet), group order
-    int ut[kLocompMax], uk[kLocompMax], usi[kLocompMax];    // neighbours as found (any order)
-    R a[kLocompMax];                  // fitted coefficients in the dictionary's dtype (:1329)
+    int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
+    int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
+    R a[NMAX];                  // fitted coefficients in the dictionary's dtype (:1329)
     R loss, last_e;                   // energyLoss of the group (:998-1014), lastEnergyResidual (:1316)
-    double b[kLocompMax];             // right-hand side <d_i, r>, then the solution
-    double diag[kLocompMax];          // original diagonal (rank test)
-    double g[kLocompMax * (kLocompMax + 1) / 2];      // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor: lower
+    double b[NMAX];             // right-hand side <d_i, r>, then the solution
+    double diag[NMAX];          // original diagonal (rank test)
+    double g[NMAX * (NMAX + 1) / 2];      // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor: lower
                                                        // triangle, row i at i (i + 1) / 2
     static __device__ __forceinline__ int at(int i, int j) { return i * (i + 1) / 2 + j; }       // (j <= i)
 };
@@ -49,6 +50,8 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kWaveApply = true;            // (no per-policy residual update: short atoms go through one wave)
     static constexpr bool kUnionRows = false;
     static constexpr bool kOwnInit = false;
+    static constexpr int kMaxGroup = kLocompMax;
+    using Lds = LocompLds<R>;
     using Base = GenericRecorr<R>;
     using Args = typename Base::Args;
     template <typename SH, typename SY>
@@ -70,6 +73,8 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = false;
+    static constexpr int kMaxGroup = kLocompMax;
+    using Lds = LocompLds<R>;
     using Base = SparseRecorr<R, false>;
     using Args = typename Base::Args;
     template <typename SH, typename SY>
@@ -101,7 +106,11 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
 // LDS: [dictionary image | weights] then per signal [control block][window x 4 | group hints][LocompLds]
 template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     using R = float;
-    static constexpr int kMaxSegments = GS == 1 ? kMaxSeg : kMfmaMaxSeg;
+    // four signals per workgroup: the per-signal state must fit a quarter of what the image leaves -- 256 segment maxima, groups of
+    // at most 32 atoms (a larger neighbourhood: stop reason 'group', the host loop)
+    static constexpr int kMaxSegments = GS == 1 ? kMaxSeg : GS == 2 ? kMfmaMaxSeg : 256;
+    static constexpr int kMaxGroup = GS <= 2 ? kLocompMax : 32;
+    using Lds = LocompLds<float, kMaxGroup>;
     static constexpr bool kFused = false;
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
@@ -110,7 +119,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static constexpr bool kScoreOnly = false;
     static constexpr int kGroup = GS;
     static constexpr int TP = 32;
-    using Shared = IterSharedT<float, kMaxSegments>;
+    using Shared = IterSharedT<float, kMaxSegments, false, true>;        // (no merge buffers of the dense re-correlation)
     using Args = MfmaArgs;
     using Sync = typename std::conditional<GS == 1, HwSync, SoftSync>::type;
     static __device__ __forceinline__ Sync make_sync(Shared& sh)
@@ -141,7 +150,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
         return ((4 * (size_t)win_floats(W) + (size_t)max_tiles(W) * TP) * sizeof(float) + 15) / 16 * 16;
     }
     static __host__ __device__ size_t image_bytes(const Args& A) { return ((size_t)A.G * S4C * 256 + 32 * (size_t)A.G) * sizeof(float); }     // (x 16)
-    static __host__ __device__ size_t policy_bytes(int W) { return front_bytes(W) + (sizeof(LocompLds<R>) + 15) / 16 * 16; }
+    static __host__ __device__ size_t policy_bytes(int W) { return front_bytes(W) + (sizeof(Lds) + 15) / 16 * 16; }
     static __host__ __device__ size_t per_signal_bytes(int W) { return ((sizeof(Shared) + 15) / 16) * 16 + policy_bytes(W); }
     static size_t total_lds_bytes(const DevParams& P, const Args& A) { return image_bytes(A) + (size_t)GS * per_signal_bytes(P.W); }
     static __device__ __forceinline__ int signal_lds_offset(const DevParams& P, const Args& A)
@@ -159,9 +168,9 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
         L.wts = L.dimg + (size_t)A.G * S4C * 256;
         return L;
     }
-    static __device__ __forceinline__ LocompLds<R>& group(const DevParams& P, const Args&, char* lds)
+    static __device__ __forceinline__ Lds& group(const DevParams& P, const Args&, char* lds)
     {
-        return *reinterpret_cast<LocompLds<R>*>(lds + front_bytes(P.W));
+        return *reinterpret_cast<Lds*>(lds + front_bytes(P.W));
     }
     // the dictionary image and the weights, once per workgroup (all its threads, hardware barrier)
     static __device__ __forceinline__ void prologue_shared(const DevParams& P, const State<R>& S, const Args& A, char* smem)
@@ -277,7 +286,8 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                                             char* plds, const R* wts, int p, int k, R c, SY& sy)
 {
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
-    LocompLds<R>& L = Pol::group(P, A, plds);
+    typename Pol::Lds& L = Pol::group(P, A, plds);
+    constexpr int kCap = Pol::kMaxGroup;
     // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
     if (tid == 0) {
         if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
@@ -296,11 +306,11 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         if (ti < nstart || ti > nend || ki == k || (ti - nstart) == p) continue;
         if (!(G.slot_a[i] != 0.0)) continue;                      // (the list-of-lists matrix drops an entry that became 0.0)
         const int o = atomicAdd(&L.cnt, 1);
-        if (o < kLocompMax - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
+        if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
     }
     sy.full();
     const int m = L.cnt;
-    if (m > kLocompMax - 1) {                                    // uniform
+    if (m > kCap - 1) {                                          // uniform
         if (tid == 0) { sh.converged = 1; sh.stop = STOP_GROUP; sh.skip = 1; }
         sy.full();
         return;

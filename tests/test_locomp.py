@@ -156,13 +156,17 @@ def test_locomp_device_loop_vs_host_loop(case, monkeypatch):
         monkeypatch.delenv('HSCMP_LOCOMP_NO_MFMA')
         assert 'mfma' not in dense.variant and np.array_equal(dense.stats, res.stats)
         # ... and so do two signals per workgroup around one dictionary image (what a batch larger than the chip runs)
-        monkeypatch.setenv('HSCMP_LOCOMP_PAIR', '1')
-        pair = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
-        monkeypatch.delenv('HSCMP_LOCOMP_PAIR')
-        assert np.array_equal(pair.stats, res.stats)
         for b in range(xs.shape[0]):
             assert (res.coefficients[b] != dense.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], dense.residuals[b])
-            assert (res.coefficients[b] != pair.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], pair.residuals[b])
+        for pack in ('2', '4'):
+            monkeypatch.setenv('HSCMP_LOCOMP_PACK', pack)
+            packed = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+            monkeypatch.delenv('HSCMP_LOCOMP_PACK')
+            if pack == '4' and 'group' in packed.stop_reasons():
+                continue                                       # (four per workgroup re-fit groups of at most 32 atoms)
+            assert np.array_equal(packed.stats, res.stats), pack
+            for b in range(xs.shape[0]):
+                assert (res.coefficients[b] != packed.coefficients[b]).nnz == 0 and np.array_equal(res.residuals[b], packed.residuals[b]), (pack, b)
     else:
         assert not (F == 1 and dtype == np.float32 and (W + 7) // 8 in (2, 4, 8))
     monkeypatch.setenv('HSCMP_LOCOMP_HOST', '1')
