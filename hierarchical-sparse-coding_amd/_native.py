@@ -181,7 +181,7 @@ class DeviceTable(object):
 
     def _check_current(self):
         if self._generation != self.engine._table_generation:
-            raise HscmpError('this DeviceTable was replaced by a later table_open on the same engine')
+            raise HscmpError('this DeviceTable was replaced by a later table_open (or a new dictionary) on the same engine')
 
     def defer_update(self, residual, lo, hi, centres):
         """Record an update (residual samples [lo, hi) changed, rows around `centres` to be re-correlated).  Nothing
@@ -288,6 +288,9 @@ class Engine(object):
         self._dict_key = key
         self.dtype, self.K, self.W, self.F = D3.dtype, K, W, F
         self._batch = None
+        # (a table opened under the previous dictionary is retired: engine_for recycles its least recently used engine, and a
+        #  handle that outlived that must fail loudly instead of reading a table of another dictionary)
+        self._table_generation = getattr(self, '_table_generation', 0) + 1
 
     def convolve1d(self, x, same):
         x2 = np.ascontiguousarray(x.reshape((x.shape[0], -1)), dtype=self.dtype)
