@@ -97,6 +97,81 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     }
 };
 
+// maximum / minimum over each 32-lane half of a wave (result in every lane of the half): quad swaps, half-row and row mirrors,
+// then row 1 (3) folds in row 0 (2) -- data-parallel primitives on the vector ALU, no LDS crossbar (ds_bpermute behind __shfl_xor
+// costs an LDS round trip per step, and the steps depend on each other)
+__device__ __forceinline__ int half_max_i32(int v, int half)
+{
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return half ? hi : lo;
+}
+__device__ __forceinline__ int half_min_i32(int v, int half)
+{
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return half ? hi : lo;
+}
+
+// One 32-position tile against all atom groups: per-position best (coefficient, atom) straight from the accumulators -- the MFMA
+// chain of an output IS the pinned sequential chain (hscmp_mfma.h: resolve_chain reproduces it bit for bit), so nothing has to be
+// recomputed.  Per accumulator element: score, compare, three selects; ascending atoms within a lane and a strict '>' keep the lowest
+// atom among equals, the two half-waves (same position, interleaved atom sets) merge with the same rule.  Result in every lane
+// (position = lane & 31).  The greedy loop's tiles keep the score only (one v_max3 per two elements) because THEIR cost is the
+// kernel's; here a tile is followed by nothing else.
+template <int S4C, bool HAS_W>
+__device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, const float* __restrict__ win, const float* __restrict__ wts,
+                                               int G, int K, int lane, float& c_out, int& k_out)
+{
+    const int j = lane & 31, h = lane >> 5;
+    const float* wb = win + j + h;
+    constexpr int NM = 4 * S4C;
+    float bop[NM];
+#pragma unroll
+    for (int s = 0; s < NM; ++s) bop[s] = wb[2 * s];
+    const f32x4* dv = reinterpret_cast<const f32x4*>(dimg) + lane;
+    float bs = -1.0f, bc = 0.0f;
+    int bk = 0;
+    for (int g = 0; g < G; ++g) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s4 = 0; s4 < S4C; ++s4) {
+            const f32x4 a = dv[(g * S4C + s4) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bop[4 * s4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bop[4 * s4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bop[4 * s4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bop[4 * s4 + 3], acc, 0, 0, 0);
+        }
+        const int kbase = 32 * g + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kbase + (r & 3) + 8 * (r >> 2);                 // atom of accumulator element r (ascending in r)
+            const float v = acc[r];
+            float sc;
+            if (HAS_W) { const float sw = v * wts[k]; sc = fabsf(sw); } else sc = fabsf(v);
+            const bool take = k < K && sc > bs;
+            bs = take ? sc : bs; bc = take ? v : bc; bk = take ? k : bk;
+        }
+    }
+    const float os = swap_halves_f(bs, h), oc = swap_halves_f(bc, h);
+    const int ok = swap_halves_i(bk, h);
+    const bool take = os > bs || (os == bs && ok < bk);
+    c_out = take ? oc : bc;
+    k_out = take ? ok : bk;
+}
+
 // Single-feature float32 signals: the re-correlation of a group atom's 2W-1 rows on the matrix cores.  The loop keeps
 // (coefficient, atom) per position like the dense form, so a tile's result -- the row's best SCORE and the 32-atom group that holds the
 // first atom attaining it (mfma_tile_score) -- is resolved right away: one chain per lane over that group's atoms (the pinned
@@ -144,11 +219,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static constexpr bool kUnionRows = true;
     static __host__ __device__ int max_tiles(int W) { return (4 * W - 1 + TP - 1) / TP; }
     static __host__ __device__ int win_floats(int W) { return max_tiles(W) * TP + 8 * S4C + 32; }        // (a multiple of 4)
-    static __host__ __device__ size_t front_bytes(int W)
-    {
-        // four copies of the window, copy c shifted by c samples: row r's window starts 16-byte aligned in copy r & 3
-        return ((4 * (size_t)win_floats(W) + (size_t)max_tiles(W) * TP) * sizeof(float) + 15) / 16 * 16;
-    }
+    static __host__ __device__ size_t front_bytes(int W) { return ((size_t)win_floats(W) * sizeof(float) + 15) / 16 * 16; }
     static __host__ __device__ size_t image_bytes(const Args& A) { return ((size_t)A.G * S4C * 256 + 32 * (size_t)A.G) * sizeof(float); }     // (x 16)
     static __host__ __device__ size_t policy_bytes(int W) { return front_bytes(W) + (sizeof(Lds) + 15) / 16 * 16; }
     static __host__ __device__ size_t per_signal_bytes(int W) { return ((sizeof(Shared) + 15) / 16) * 16 + policy_bytes(W); }
@@ -157,13 +228,12 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     {
         return __builtin_amdgcn_readfirstlane((int)image_bytes(A) + (GS == 1 ? 0 : gsig() * (int)per_signal_bytes(P.W)));
     }
-    struct Lay { float* win; int* hint; float* dimg; float* wts; int wf; };
+    struct Lay { float* win; float* dimg; float* wts; int wf; };
     static __device__ __forceinline__ Lay layout(const DevParams& P, const Args& A, char* lds)
     {
         Lay L;
         L.wf = win_floats(P.W);
         L.win = reinterpret_cast<float*>(lds);
-        L.hint = reinterpret_cast<int*>(L.win + 4 * L.wf);
         L.dimg = reinterpret_cast<float*>(dyn_lds());
         L.wts = L.dimg + (size_t)A.G * S4C * 256;
         return L;
@@ -203,12 +273,13 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     // signal.  Samples outside it: none when `interior`; else reflected about the slice [sidx, sidx + nslice) (np.pad 'reflect',
     // :1046), or zero (nslice < 0: the initial correlation, :159-164)
     static __device__ __forceinline__ void rows(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int t0, int nrows,
-                                                bool interior, int sidx, int nslice, Sync& sy)
+                                                bool interior, int sidx, int nslice, Sync& sy, bool timed = false)
     {
         const Lay L = layout(P, A, lds);
         const int T = P.T, W = P.W, tid = ltid(), lane = tid & 63, wv = tid >> 6;
         const int span = nrows + W - 1, wstart = t0 - P.off;
-        for (int i = tid; i < L.wf + 3; i += kThreads) {
+        HSCMP_STAMP_BEGIN();
+        for (int i = tid; i < L.wf; i += kThreads) {
             float v = 0.0f;
             if (i < span) {
                 const int gi = wstart + i;
@@ -216,41 +287,19 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
                 else if (nslice < 0) v = (gi >= 0 && gi < T) ? G.r[gi] : 0.0f;
                 else v = G.r[reflect_index(gi, sidx, nslice)];
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (i - c >= 0 && i - c < L.wf) L.win[c * L.wf + i - c] = v;   // copy c: win_c[j] = win[j + c]
+            L.win[i] = v;
         }
         sy.lds();
+        if (timed) HSCMP_STAMP(10);                            // window
         const int nt = (nrows + TP - 1) / TP;
         for (int q = wv; q < nt; q += kWaves) {
-            int grp;
-            (void)mfma_tile_score<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, S4C, lane, grp);
-            if (lane < TP) L.hint[TP * q + lane] = grp;
+            float c; int k;
+            mfma_tile_best<S4C, HAS_W>(L.dimg, L.win + TP * q, L.wts, A.G, P.K, lane, c, k);
+            const int row = TP * q + lane, t = t0 + row;
+            if (lane < TP && row < nrows && t >= 0 && t < T) { G.bc[t] = c; G.bk[t] = k; }      // overlapReplace clipping (utils.py:133-161)
         }
-        sy.lds();
-        // two rows per wave and pass (one per half-wave): lane l & 31 runs the chain of atom 32 g + (l & 31) of the row's group
-        const int half = lane >> 5, l5 = lane & 31;
-        for (int pr = wv; 2 * pr < nrows; pr += kWaves) {
-            const int row = 2 * pr + half;
-            const int rq = row < nrows ? row : nrows - 1;
-            const int t = t0 + rq;
-            const int k = 32 * L.hint[rq] + l5;
-            float bc = 0.0f;
-            int sb = __float_as_int(-1.0f);
-            if (k < P.K) {
-                bc = resolve_chain<S4C>(L.dimg, L.win + (rq & 3) * L.wf + (rq & ~3), k, S4C);
-                float sc;
-                if (HAS_W) { const float sw = bc * L.wts[k]; sc = fabsf(sw); } else sc = fabsf(bc);
-                sb = __float_as_int(sc);                       // (scores are >= 0: their bit patterns order like the values)
-            }
-            int m = sb;
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-            int idx = sb == m ? k : INT_MAX;                   // the lowest atom among equals (np.argmax)
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) idx = min(idx, __shfl_xor(idx, d));
-            const float c = __shfl(bc, (lane & 32) | (idx & 31));
-            if (l5 == 0 && row < nrows && t >= 0 && t < T) { G.bc[t] = c; G.bk[t] = idx; }      // overlapReplace clipping (utils.py:133-161)
-        }
+        if (timed) HSCMP_STAMP(11);                            // tiles
+        if (timed) HSCMP_STAMP(12);                            // rows resolved
     }
     // rows p-(W-1) .. p+(W-1) around one atom (:1018-1051)
     template <typename SH>
@@ -259,13 +308,13 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
         const int T = P.T, W = P.W;
         const int tstart = p - P.off - (W - 1), tend = p + W / 2 + (W - 1);          // :1028-1038
         const int sidx = tstart < 0 ? 0 : tstart, eidx = tend > T - 1 ? T - 1 : tend;
-        rows(P, G, A, lds, p - (W - 1), 2 * W - 1, tstart >= 0 && tend <= T - 1, sidx, eidx - sidx + 1, sy);
+        rows(P, G, A, lds, p - (W - 1), 2 * W - 1, tstart >= 0 && tend <= T - 1, sidx, eidx - sidx + 1, sy, true);
     }
     // the rows of a group of atoms between pmin and pmax, none of which reaches a signal end: a row's value only depends on the
     // final residual, so the union of their row ranges is computed once
     static __device__ __forceinline__ void lrun_span(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax, Sync& sy)
     {
-        rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0, sy);
+        rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0, sy, true);
     }
     // (the step-by-step atom body of the greedy loop is never instantiated for a kLocomp policy, but must compile)
     template <typename SH>
@@ -288,6 +337,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
     typename Pol::Lds& L = Pol::group(P, A, plds);
     constexpr int kCap = Pol::kMaxGroup;
+    HSCMP_STAMP_BEGIN();
     // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
     if (tid == 0) {
         if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
@@ -309,6 +359,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
     }
     sy.full();
+    HSCMP_STAMP(0);                                              // neighbourhood scan
     const int m = L.cnt;
     if (m > kCap - 1) {                                          // uniform
         if (tid == 0) { sh.converged = 1; sh.stop = STOP_GROUP; sh.skip = 1; }
@@ -325,6 +376,10 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     if (tid == 0) { L.n = 1 + m; L.a[0] = c; }
     sy.full();
     const int n = 1 + m;
+    HSCMP_STAMP(1);                                              // group order
+#ifdef HSCMP_DBG_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[14] += 1; g_stamps[15] += (unsigned long long)n; }
+#endif
 
     if (n > 1) {
         // ---- :1322-1329 least squares of the local residual on the group's (clipped) atoms: G x = b, float64
@@ -359,6 +414,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             }
         }
         sy.full();
+        HSCMP_STAMP(2);                                          // right-hand sides + Gram entries
         // Cholesky of the Gram matrix by one wave (lane = row), right-looking; a pivot that vanishes against its own diagonal
         // marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
         if (wv == 0) {
@@ -398,6 +454,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             }
         }
         sy.full();
+        HSCMP_STAMP(3);                                          // Cholesky + substitutions
     }
 
     // ---- :1336-1341 / :1345-1350 coefficients += fitted; residual -= fitted * atom, with the local energies (:996-1016)
@@ -508,6 +565,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         if (tid == 0) { const R l = pb - pa; L.loss = L.loss + l; }     // :1005 summed over the group
         sy.full();                                                       // the residual writes of this atom are visible to the next
     }
+    HSCMP_STAMP(4);                                                      // coefficients, subtractions, local energies
     if (tid == 0) sh.e_res = sh.e_res - L.loss;                          // :1014
     if (P.has_scale)
         for (int gi = 0; gi < n; ++gi) {
@@ -536,6 +594,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         Pol::lrun(P, S, G, sh, A, plds, L.t[gi], L.k[gi], sy);
         sy.full();
     }
+    HSCMP_STAMP(5);                                                      // re-correlation
     for (int gi = 0; gi < n; ++gi) {
         const int tp = L.t[gi];
         const int lo = max(0, tp - (W - 1)), hi = min(T - 1, tp + (W - 1));
@@ -548,6 +607,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     }
 
     // ---- :1357-1383 fast stop rules
+    HSCMP_STAMP(6);                                                      // segments marked / rescanned
     if (tid == 0) {
         sh.iters += 1;
         if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
