@@ -67,7 +67,8 @@ struct hscmp_ctx {
     int* d_slot_t = nullptr; int* d_slot_k = nullptr; double* d_slot_a = nullptr;
     unsigned long long* d_hkey = nullptr; int* d_hval = nullptr;   // slot hash table [B][hmask+1]
     int* d_head = nullptr;     // [B][T] slot chains by position (round-parallel loop)
-    size_t cap_hkey = 0, cap_hval = 0, cap_head = 0;
+    double* d_lgram = nullptr; // [B][kLgramDoubles] LoCOMP: Gram matrices beyond the LDS copy
+    size_t cap_hkey = 0, cap_hval = 0, cap_head = 0, cap_lgram = 0;
     int* d_sel_t = nullptr; int* d_sel_k = nullptr; void* d_sel_c = nullptr;
     int* d_stats = nullptr; void* d_energy = nullptr; unsigned long long* d_edge = nullptr;
     DevParams P{};
@@ -169,7 +170,7 @@ static void free_all(hscmp_ctx* c)
 {
     for (void* p : c->d_epi) if (p) (void)hipFree(p);
     void* ptrs[] = {c->d_D, c->d_w, c->d_Dfrag, c->d_Dt, c->d_Dc, c->d_nzptr, c->d_nzwf, c->d_nzval, c->d_fptr, c->d_fkw, c->d_fval, c->d_rl_cnt, c->d_rl_f, c->d_scratch, c->d_rowflag, c->d_x, c->d_resid, c->d_best_c, c->d_best_k, c->d_ev_t, c->d_ev_k, c->d_ev_c,
-                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_hkey, c->d_hval, c->d_head, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
+                    c->d_slot_t, c->d_slot_k, c->d_slot_a, c->d_hkey, c->d_hval, c->d_head, c->d_lgram, c->d_sel_t, c->d_sel_k, c->d_sel_c, c->d_stats, c->d_energy, c->d_edge};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -424,6 +425,7 @@ static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, s
         {(void**)&ctx->d_hkey, &ctx->cap_hkey, B * ((size_t)P.hmask + 1) * sizeof(unsigned long long)},
         {(void**)&ctx->d_hval, &ctx->cap_hval, B * ((size_t)P.hmask + 1) * sizeof(int)},
         {(void**)&ctx->d_head, &ctx->cap_head, P.blocked ? B * T * sizeof(int) : 0},
+        {(void**)&ctx->d_lgram, &ctx->cap_lgram, ctx->method == HSCMP_METHOD_LOCOMP ? B * (size_t)kLgramDoubles * sizeof(double) : 0},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {
@@ -446,7 +448,7 @@ template <typename R> static State<R> make_state(hscmp_ctx* c)
     S.residual = (R*)c->d_resid; S.best_c = (R*)c->d_best_c; S.best_k = c->d_best_k;
     S.ev_t = c->d_ev_t; S.ev_k = c->d_ev_k; S.ev_c = (R*)c->d_ev_c;
     S.slot_t = c->d_slot_t; S.slot_k = c->d_slot_k; S.slot_a = c->d_slot_a;
-    S.hkey = c->d_hkey; S.hval = c->d_hval; S.head = c->d_head;
+    S.hkey = c->d_hkey; S.hval = c->d_hval; S.head = c->d_head; S.lgram = c->d_lgram;
     S.sel_t = c->d_sel_t; S.sel_k = c->d_sel_k; S.sel_c = (R*)c->d_sel_c;
     S.stats = c->d_stats; S.energy = (R*)c->d_energy; S.edge = c->d_edge;
     return S;
@@ -628,11 +630,11 @@ template <int S4C, bool HAS_W, int GS> static int launch_iterate_locomp_mfma_g(h
 }
 template <int S4C, bool HAS_W> static int launch_iterate_locomp_mfma_t(hscmp_ctx* ctx, const DevParams& P, bool dry)
 {
-    // signals per workgroup: two when the batch has more signals than the chip has CUs.  (HSCMP_LOCOMP_PACK = 1 / 2 / 4 overrides.  Four
-    // per workgroup leave each signal a group capacity of 32 atoms: at BASELINE config 4 -- 2000 coefficients per signal, the
-    // largest neighbourhoods 30-56 atoms -- most signals would outgrow it and fall back to the host loop; not chosen automatically.)
+    // signals per workgroup: as many as it takes to put the whole batch on the chip at once -- two or four around one dictionary
+    // image, their tiles sharing the CU's matrix pipe (HSCMP_LOCOMP_PACK = 1 / 2 / 4 overrides)
     const char* e = getenv("HSCMP_LOCOMP_PACK");
-    const int pack = e ? atoi(e) : P.B > mfma_device_cus() ? 2 : 1;
+    const int cus = mfma_device_cus();
+    const int pack = e ? atoi(e) : P.B > 2 * cus ? 4 : P.B > cus ? 2 : 1;
     if (pack >= 4 && launch_iterate_locomp_mfma_g<S4C, HAS_W, 4>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 4>(ctx, P, dry);
     if (pack >= 2 && launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, true) == 0) return launch_iterate_locomp_mfma_g<S4C, HAS_W, 2>(ctx, P, dry);
     return launch_iterate_locomp_mfma_g<S4C, HAS_W, 1>(ctx, P, dry);

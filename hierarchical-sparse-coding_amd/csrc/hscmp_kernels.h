@@ -602,6 +602,7 @@ template <typename R> struct Sig {   // per-signal views
     unsigned long long* hkey; int* hval;
     int* sel_t; int* sel_k; R* sel_c;
     int* head;          // (round-parallel loop only)
+    double* lgram;      // (LoCOMP only: Gram matrix of a group too large for its LDS copy)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,6 +1001,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
     G.head = S.head;
+    G.lgram = S.lgram ? S.lgram + (int64_t)b * kLgramDoubles : nullptr;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
         g_blk[3 * b + 0] = wall_clock64();

@@ -31,7 +31,7 @@ constexpr int kLocompMax = 64;        // atoms of a group, the selected one incl
 // coefficient (the hierarchical per-signal entry therefore keeps the reference's own LAPACK call on the host).
 constexpr double kLocompDead = 1e-12;
 
-template <typename R, int NMAX = kLocompMax> struct LocompLds {
+template <typename R, int NMAX = kLocompMax, int NG = NMAX> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
     int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
     int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
@@ -39,8 +39,10 @@ template <typename R, int NMAX = kLocompMax> struct LocompLds {
     R loss, last_e;                   // energyLoss of the group (:998-1014), lastEnergyResidual (:1316)
     double b[NMAX];             // right-hand side <d_i, r>, then the solution
     double diag[NMAX];          // original diagonal (rank test)
-    double g[NMAX * (NMAX + 1) / 2];      // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor: lower
+    double g[NG * (NG + 1) / 2];          // Gram matrix <d_i, d_j> of the clipped atoms, then its Cholesky factor: lower
                                                        // triangle, row i at i (i + 1) / 2
+                                          // (a group of more than NG atoms keeps it in global memory: Sig::lgram)
+    static constexpr int kLdsGroup = NG;
     static __device__ __forceinline__ int at(int i, int j) { return i * (i + 1) / 2 + j; }       // (j <= i)
 };
 
@@ -181,11 +183,11 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
 // LDS: [dictionary image | weights] then per signal [control block][window x 4 | group hints][LocompLds]
 template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     using R = float;
-    // four signals per workgroup: the per-signal state must fit a quarter of what the image leaves -- 256 segment maxima, groups of
-    // at most 32 atoms (a larger neighbourhood: stop reason 'group', the host loop)
+    // four signals per workgroup: the per-signal state must fit a quarter of what the image leaves -- 256 segment maxima, the Gram
+    // matrix of a group in LDS up to 32 atoms
     static constexpr int kMaxSegments = GS == 1 ? kMaxSeg : GS == 2 ? kMfmaMaxSeg : 256;
-    static constexpr int kMaxGroup = GS <= 2 ? kLocompMax : 32;
-    using Lds = LocompLds<float, kMaxGroup>;
+    static constexpr int kMaxGroup = kLocompMax;
+    using Lds = LocompLds<float, kLocompMax, (GS <= 2 ? kLocompMax : 32)>;       // (four per workgroup: Gram matrices beyond 32 atoms in global memory)
     static constexpr bool kFused = false;
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
@@ -381,6 +383,11 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[14] += 1; g_stamps[15] += (unsigned long long)n; }
 #endif
 
+    // the Gram matrix: in LDS, or -- a group larger than the policy keeps there -- in the signal's global scratch (through L2)
+    const bool big = n > Pol::Lds::kLdsGroup;                // uniform
+    double* gglob = G.lgram;
+    auto gl = [&](int idx) -> double { return big ? __hip_atomic_load(gglob + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : L.g[idx]; };
+    auto gs = [&](int idx, double v) { if (big) __hip_atomic_store(gglob + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else L.g[idx] = v; };
     if (n > 1) {
         // ---- :1322-1329 least squares of the local residual on the group's (clipped) atoms: G x = b, float64
         // items: n right-hand sides, then the n (n + 1) / 2 Gram entries; one wave per item, lanes over the elements
@@ -410,7 +417,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     for (int x = lane; x < (hi - lo) * F; x += 64) acc += (double)di[x] * (double)dj[x];
                     acc = wave_sum_f64(acc);
                 }
-                if (lane == 0) { L.g[L.at(i, j)] = acc; if (i == j) L.diag[i] = acc; }
+                if (lane == 0) { gs(L.at(i, j), acc); if (i == j) L.diag[i] = acc; }
             }
         }
         sy.full();
@@ -419,35 +426,35 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         // marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
         if (wv == 0) {
             for (int j = 0; j < n; ++j) {
-                const double piv = L.g[L.at(j, j)];
+                const double piv = gl(L.at(j, j));
                 const bool dead = !(piv > kLocompDead * L.diag[j]);            // uniform
                 const double ljj = dead ? 0.0 : sqrt(piv);
-                if (lane == 0) L.g[L.at(j, j)] = ljj;
+                if (lane == 0) gs(L.at(j, j), ljj);
                 if (lane > j && lane < n) {
-                    const double lij = dead ? 0.0 : L.g[L.at(lane, j)] / ljj;
-                    L.g[L.at(lane, j)] = lij;
+                    const double lij = dead ? 0.0 : gl(L.at(lane, j)) / ljj;
+                    gs(L.at(lane, j), lij);
                 }
                 __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 if (lane > j && lane < n) {
-                    const double lij = L.g[L.at(lane, j)];
-                    for (int q = j + 1; q <= lane; ++q) L.g[L.at(lane, q)] -= lij * L.g[L.at(q, j)];
+                    const double lij = gl(L.at(lane, j));
+                    for (int q = j + 1; q <= lane; ++q) gs(L.at(lane, q), gl(L.at(lane, q)) - lij * gl(L.at(q, j)));
                 }
                 __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
             if (lane == 0) {
                 // forward (L y = b), then backward (L^T x = y); a dead atom keeps 0
                 for (int i = 0; i < n; ++i) {
                     double v = L.b[i];
-                    for (int q = 0; q < i; ++q) v -= L.g[L.at(i, q)] * L.b[q];
-                    const double d = L.g[L.at(i, i)];
+                    for (int q = 0; q < i; ++q) v -= gl(L.at(i, q)) * L.b[q];
+                    const double d = gl(L.at(i, i));
                     L.b[i] = d > 0.0 ? v / d : 0.0;
                 }
                 for (int i = n - 1; i >= 0; --i) {
                     double v = L.b[i];
-                    for (int q = i + 1; q < n; ++q) v -= L.g[L.at(q, i)] * L.b[q];
-                    const double d = L.g[L.at(i, i)];
+                    for (int q = i + 1; q < n; ++q) v -= gl(L.at(q, i)) * L.b[q];
+                    const double d = gl(L.at(i, i));
                     L.b[i] = d > 0.0 ? v / d : 0.0;
                 }
                 for (int i = 0; i < n; ++i) L.a[i] = (R)L.b[i];

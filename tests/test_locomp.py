@@ -223,6 +223,34 @@ def test_locomp_random_configuration_device_loop_vs_host_loop(i, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_locomp_groups_beyond_the_lds_copy_with_four_signals_per_workgroup(monkeypatch):
+    """Four signals per workgroup keep the Gram matrix of a group in LDS up to 32 atoms; a larger group (up to the kernel's 64)
+    solves through the signal's global scratch.  Dense codes -- neighbourhoods of 33+ atoms -- through one, two and four signals
+    per workgroup: bit-identical."""
+    from hsc_amd.modeling import LoCOMP
+    rs = np.random.RandomState(11)
+    T, K, W = 1200, 70, 64
+    D = rs.standard_normal((K, W)).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=1, keepdims=True))
+    xs = rs.standard_normal((6, T)).astype(np.float32)
+    kw = dict(toleranceSnr=17.0, nbBlocks=3)
+    out = {}
+    for pack in ('1', '2', '4'):
+        monkeypatch.setenv('HSCMP_LOCOMP_PACK', pack)
+        out[pack] = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+        assert 'locomp_mfma' in out[pack].variant and 'group' not in out[pack].stop_reasons(), pack
+    monkeypatch.delenv('HSCMP_LOCOMP_PACK')
+    # the codes are dense enough: some atom has more than 32 others within the neighbourhood's reach
+    c = out['1'].coefficients[0].tocoo()
+    t = np.sort(c.row)
+    assert (np.searchsorted(t, t + W - 2, side='right') - np.searchsorted(t, t - (W - 2))).max() > 36      # (reach of :1228-1236: about +-W)
+    for pack in ('2', '4'):
+        assert np.array_equal(out[pack].stats, out['1'].stats), pack
+        for b in range(xs.shape[0]):
+            assert (out[pack].coefficients[b] != out['1'].coefficients[b]).nnz == 0 and np.array_equal(out[pack].residuals[b], out['1'].residuals[b]), (pack, b)
+
+
+@pytest.mark.gpu
 def test_locomp_neighbourhood_beyond_the_kernel_capacity_goes_to_the_host_loop():
     """More than 63 previously selected atoms around a new one (short filters, many atoms per position, a demanding SNR):
     the kernel stops the signal with reason 'group' before applying anything of that atom, and the batch entry repeats the
