@@ -274,7 +274,7 @@ template <typename R> struct State {
     int* head;          // [B][T] round-parallel loop: most recent coefficient slot at position t (-1: none), chained through hval
     double* lgram;      // [B][kLgramDoubles] LoCOMP: packed Gram matrix of a group that outgrows its LDS copy (nullptr: other methods)
 };
-constexpr int kLgramDoubles = 64 * 65 / 2;     // (kLocompMax atoms, hscmp_locomp.h)
+constexpr int kLgramDoubles = 128 * 129 / 2;   // (kLocompMax atoms, hscmp_locomp.h)
 
 __device__ __forceinline__ float rabs(float v) { return fabsf(v); }
 __device__ __forceinline__ double rabs(double v) { return fabs(v); }

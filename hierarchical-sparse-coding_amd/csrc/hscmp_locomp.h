@@ -22,8 +22,8 @@
 
 namespace hscmp {
 
-constexpr int kLocompMax = 64;        // atoms of a group, the selected one included (larger: STOP_GROUP, the host loop takes over); a policy
-                                      // that packs several signals into a workgroup may take fewer (Pol::kMaxGroup)
+constexpr int kLocompMax = 128;       // atoms of a group, the selected one included (larger: STOP_GROUP, the host loop takes over)
+constexpr int kLocompLds = 64;        // ... whose Gram matrix stays in LDS (larger groups: the signal's global scratch, Sig::lgram)
 // Nearly dependent atoms in a group (a Cholesky pivot that all but vanishes against its diagonal entry): the re-fit is solved in
 // float64 whatever the dictionary's dtype, an atom the others already span keeps coefficient 0.  The reference's pseudo-inverse is
 // an SVD in the DICTIONARY's dtype with a cut-off of 1e-15: on such a group its float32 result is round-off amplified by the
@@ -31,7 +31,7 @@ constexpr int kLocompMax = 64;        // atoms of a group, the selected one incl
 // coefficient (the hierarchical per-signal entry therefore keeps the reference's own LAPACK call on the host).
 constexpr double kLocompDead = 1e-12;
 
-template <typename R, int NMAX = kLocompMax, int NG = NMAX> struct LocompLds {
+template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
     int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
     int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
@@ -60,7 +60,8 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static __device__ __forceinline__ void lrun(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const Args& A, char* lds, int p, int k, SY&)
     { Base::run(P, S, G, sh, A, lds, p, k); }
     template <typename SY>
-    static __device__ __forceinline__ void lrun_span(const DevParams&, const Sig<R>&, const Args&, char*, int, int, SY&) {}
+    static __device__ __forceinline__ void lrun_span(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int, SY&) {}
+    static __device__ __forceinline__ bool atom_lists(const DevParams&, const Args&, char*, const int*&, const int*&, const R*&) { return false; }
     static size_t extra_lds_bytes(const DevParams& P) { return Base::extra_lds_bytes(P) + sizeof(LocompLds<R>) + 16; }
     static __device__ __forceinline__ LocompLds<R>& group(const DevParams&, const Args&, char* lds)
     {
@@ -74,7 +75,7 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
 template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
-    static constexpr bool kUnionRows = false;
+    static constexpr bool kUnionRows = true;
     static constexpr int kMaxGroup = kLocompMax;
     using Lds = LocompLds<R>;
     using Base = SparseRecorr<R, false>;
@@ -82,8 +83,30 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     template <typename SH, typename SY>
     static __device__ __forceinline__ void lrun(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const Args& A, char* lds, int p, int k, SY&)
     { Base::run(P, S, G, sh, A, lds, p, k); }
+    // the non-zeros of the atoms (k -> [nzptr[k], nzptr[k+1]) of (w << 16 | f, value)): right-hand sides and Gram entries of a group
+    // are sums over a handful of them instead of W x F products
+    static __device__ __forceinline__ bool atom_lists(const DevParams& P, const Args& A0, char* lds, const int*& nzptr, const int*& nzwf, const R*& nzval)
+    {
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        nzptr = A.nzptr; nzwf = A.nzwf; nzval = A.nzval;
+        return A.nzptr != nullptr;
+    }
+    // the rows of a group of interior atoms between pmin and pmax, once: 2W-1 rows at a time (the capacity of sparse_rows), no
+    // padding involved (every window lies inside the signal)
     template <typename SY>
-    static __device__ __forceinline__ void lrun_span(const DevParams&, const Sig<R>&, const Args&, char*, int, int, SY&) {}
+    static __device__ __forceinline__ void lrun_span(const DevParams& P, const State<R>& S, const Sig<R>& G, const Args& A0, char* lds, int pmin, int pmax, SY&)
+    {
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        unsigned* bits = Base::has_bits(P, A) ? Base::bits_of(P, A0, lds) : nullptr;
+        if (bits) {                                          // (no row lists: the rows the group's subtractions may have filled)
+            const int lo = max(0, pmin - (P.W - 1) / 2), hi = min(P.T, pmax + P.W / 2 + 1);
+            for (int t = lo + (int)threadIdx.x; t < hi; t += kThreads) atomicOr(&bits[t >> 5], 1u << (t & 31));
+        }                                                    // (ordered by the first barrier of gather_window)
+        const int first = pmin - (P.W - 1), nrows = (pmax - pmin) + 2 * P.W - 1, step = 2 * P.W - 1;
+        for (int r0 = 0; r0 < nrows; r0 += step)
+            sparse_rows<R, false>(P, S, G, A, L, bits, first + r0, min(step, nrows - r0), false, 0, 0, false);
+    }
     static size_t policy_bytes(const DevParams& P, const Args& A) { return ((Base::extra_lds_bytes(P, A) + 15) / 16) * 16; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return policy_bytes(P, A) + sizeof(LocompLds<R>) + 16; }
     static __device__ __forceinline__ LocompLds<R>& group(const DevParams& P, const Args& A, char* lds)
@@ -187,7 +210,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     // matrix of a group in LDS up to 32 atoms
     static constexpr int kMaxSegments = GS == 1 ? kMaxSeg : GS == 2 ? kMfmaMaxSeg : 256;
     static constexpr int kMaxGroup = kLocompMax;
-    using Lds = LocompLds<float, kLocompMax, (GS <= 2 ? kLocompMax : 32)>;       // (four per workgroup: Gram matrices beyond 32 atoms in global memory)
+    using Lds = LocompLds<float, kLocompMax, (GS <= 2 ? kLocompLds : 32)>;       // (four per workgroup: Gram matrices beyond 32 atoms in global memory)
     static constexpr bool kFused = false;
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
@@ -215,6 +238,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static __device__ __forceinline__ bool row_results(const DevParams&, const Args&, char*, int, const int*&, const R*&, const R*&, int&, int&) { return false; }
     static __device__ __forceinline__ bool residual_copy_in_lds(const Args&, char*) { return false; }
     static __device__ __forceinline__ void before_runs(const Args&, char*) {}
+    static __device__ __forceinline__ bool atom_lists(const DevParams&, const Args&, char*, const int*&, const int*&, const R*&) { return false; }
 
     // rows of one re-correlation: 2W-1 around one atom, or the union over a group of interior atoms -- their positions lie within
     // [p - W, p + W] of the selected atom (:1228-1236), so at most 4W-1 rows
@@ -314,7 +338,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     }
     // the rows of a group of atoms between pmin and pmax, none of which reaches a signal end: a row's value only depends on the
     // final residual, so the union of their row ranges is computed once
-    static __device__ __forceinline__ void lrun_span(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax, Sync& sy)
+    static __device__ __forceinline__ void lrun_span(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax, Sync& sy)
     {
         rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0, sy, true);
     }
@@ -392,6 +416,37 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         // ---- :1322-1329 least squares of the local residual on the group's (clipped) atoms: G x = b, float64
         // items: n right-hand sides, then the n (n + 1) / 2 Gram entries; one wave per item, lanes over the elements
         const int nitems = n + n * (n + 1) / 2;
+        const int* nzp = nullptr; const int* nzwf = nullptr; const R* nzv = nullptr;
+        if (Pol::atom_lists(P, A, plds, nzp, nzwf, nzv)) {           // uniform
+            // sparse dictionary: one thread per item, sums over the atoms' non-zeros (a clipped atom loses the rows outside the signal)
+            for (int it = tid; it < nitems; it += kThreads) {
+                double acc = 0.0;
+                if (it < n) {
+                    const int ti = L.t[it] - P.off, ki = L.k[it];
+                    for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
+                        const int wf = nzwf[e], row = ti + (wf >> 16);
+                        if (row >= 0 && row < T) acc += (double)nzv[e] * (double)G.r[(int64_t)row * F + (wf & 0xffff)];
+                    }
+                    L.b[it] = acc;
+                } else {
+                    int q = it - n, i = 0;
+                    while ((i + 1) * (i + 2) / 2 <= q) ++i;
+                    const int j = q - i * (i + 1) / 2;
+                    const int ti = L.t[i] - P.off, tj = L.t[j] - P.off, ki = L.k[i], kj = L.k[j];
+                    const int ej0 = nzp[kj], ej1 = nzp[kj + 1];
+                    for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
+                        const int wf = nzwf[e], row = ti + (wf >> 16);
+                        if (row < 0 || row >= T) continue;
+                        const int want = ((row - tj) << 16) | (wf & 0xffff);             // the same cell seen from atom j
+                        if (row - tj < 0 || row - tj >= W) continue;
+                        for (int e2 = ej0; e2 < ej1; ++e2)
+                            if (nzwf[e2] == want) acc += (double)nzv[e] * (double)nzv[e2];
+                    }
+                    gs(L.at(i, j), acc);
+                    if (i == j) L.diag[i] = acc;
+                }
+            }
+        } else
         for (int it = wv; it < nitems; it += kWaves) {
             double acc = 0.0;
             if (it < n) {
@@ -422,24 +477,26 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         }
         sy.full();
         HSCMP_STAMP(2);                                          // right-hand sides + Gram entries
-        // Cholesky of the Gram matrix by one wave (lane = row), right-looking; a pivot that vanishes against its own diagonal
-        // marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
+        // Cholesky of the Gram matrix by one wave (lane = rows lane, lane + 64), right-looking; a pivot that vanishes against its own
+        // diagonal marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
         if (wv == 0) {
             for (int j = 0; j < n; ++j) {
                 const double piv = gl(L.at(j, j));
                 const bool dead = !(piv > kLocompDead * L.diag[j]);            // uniform
                 const double ljj = dead ? 0.0 : sqrt(piv);
                 if (lane == 0) gs(L.at(j, j), ljj);
-                if (lane > j && lane < n) {
-                    const double lij = dead ? 0.0 : gl(L.at(lane, j)) / ljj;
-                    gs(L.at(lane, j), lij);
-                }
+                for (int r = lane; r < n; r += 64)
+                    if (r > j) {
+                        const double lij = dead ? 0.0 : gl(L.at(r, j)) / ljj;
+                        gs(L.at(r, j), lij);
+                    }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                if (lane > j && lane < n) {
-                    const double lij = gl(L.at(lane, j));
-                    for (int q = j + 1; q <= lane; ++q) gs(L.at(lane, q), gl(L.at(lane, q)) - lij * gl(L.at(q, j)));
-                }
+                for (int r = lane; r < n; r += 64)
+                    if (r > j) {
+                        const double lij = gl(L.at(r, j));
+                        for (int q = j + 1; q <= r; ++q) gs(L.at(r, q), gl(L.at(r, q)) - lij * gl(L.at(q, j)));
+                    }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
@@ -594,7 +651,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             pmin = min(pmin, tp); pmax = max(pmax, tp);
         }
     if (joint && pmax - pmin <= 2 * W) {
-        Pol::lrun_span(P, G, A, plds, pmin, pmax, sy);
+        Pol::lrun_span(P, S, G, A, plds, pmin, pmax, sy);
         sy.full();
     } else
     for (int gi = 0; gi < n; ++gi) {

@@ -225,7 +225,7 @@ def test_locomp_random_configuration_device_loop_vs_host_loop(i, monkeypatch):
 @pytest.mark.gpu
 def test_locomp_groups_beyond_the_lds_copy_with_four_signals_per_workgroup(monkeypatch):
     """Four signals per workgroup keep the Gram matrix of a group in LDS up to 32 atoms; a larger group (up to the kernel's 64)
-    solves through the signal's global scratch.  Dense codes -- neighbourhoods of 33+ atoms -- through one, two and four signals
+    solves through the signal's global scratch (up to the kernel's 128).  Dense codes -- neighbourhoods of 33+ atoms -- through one, two and four signals
     per workgroup: bit-identical."""
     from hsc_amd.modeling import LoCOMP
     rs = np.random.RandomState(11)
@@ -252,12 +252,12 @@ def test_locomp_groups_beyond_the_lds_copy_with_four_signals_per_workgroup(monke
 
 @pytest.mark.gpu
 def test_locomp_neighbourhood_beyond_the_kernel_capacity_goes_to_the_host_loop():
-    """More than 63 previously selected atoms around a new one (short filters, many atoms per position, a demanding SNR):
+    """More than 127 previously selected atoms around a new one (short filters, many atoms per position, a demanding SNR):
     the kernel stops the signal with reason 'group' before applying anything of that atom, and the batch entry repeats the
     signal on the host loop -- the result is the host loop's, the other signals keep the device loop's."""
     from hsc_amd.modeling import LoCOMP
     rs = np.random.RandomState(4)
-    K, W, T, F = 40, 5, 60, 12                                # (a neighbourhood spans ~3W x F = 180 dimensions: room for > 63 atoms)
+    K, W, T, F = 60, 5, 60, 24                                # (a neighbourhood spans ~3W x F = 360 dimensions: room for > 127 atoms)
     D = rs.standard_normal((K, W, F)).astype(np.float64)
     D /= np.sqrt(np.sum(D ** 2, axis=(1, 2), keepdims=True))
     dense = rs.standard_normal((T, F))
