@@ -13,7 +13,9 @@
 //   :1368-1383  `coefficients.nnz` (stored non-zeros: an entry that cancels to 0.0 leaves the count) is what nbNonzeroCoefs
 //               is compared with, and the loop also stops when an atom changes the residual energy by less than eps.
 // Selection, weak-atom filter, residual subtraction with its local energies, local re-correlation and the round-level stop
-// rules are those of the greedy loop and run through the same code (GenericRecorr: the table-free dense form).
+// rules are those of the greedy loop and run through the same code.  Three policies: LocompRecorr (the table-free dense form, any
+// shape), LocompSparse (multi-feature inputs with a sparse dictionary: hierarchical levels >= 1), LocompMfma (single-feature float32:
+// re-correlations and the initial correlation on the matrix cores, up to four signals per workgroup around one dictionary image).
 // Parity is at tolerance level by construction (the reference's pseudo-inverse is an SVD in the dictionary's dtype).
 #pragma once
 #include "hscmp_kernels.h"
@@ -122,32 +124,6 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     }
 };
 
-// maximum / minimum over each 32-lane half of a wave (result in every lane of the half): quad swaps, half-row and row mirrors,
-// then row 1 (3) folds in row 0 (2) -- data-parallel primitives on the vector ALU, no LDS crossbar (ds_bpermute behind __shfl_xor
-// costs an LDS round trip per step, and the steps depend on each other)
-__device__ __forceinline__ int half_max_i32(int v, int half)
-{
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1" : "+v"(v));
-    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
-    return half ? hi : lo;
-}
-__device__ __forceinline__ int half_min_i32(int v, int half)
-{
-    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1" : "+v"(v));
-    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
-    return half ? hi : lo;
-}
-
 // One 32-position tile against all atom groups: per-position best (coefficient, atom) straight from the accumulators -- the MFMA
 // chain of an output IS the pinned sequential chain (hscmp_mfma.h: resolve_chain reproduces it bit for bit), so nothing has to be
 // recomputed.  Per accumulator element: score, compare, three selects; ascending atoms within a lane and a strict '>' keep the lowest
@@ -197,13 +173,12 @@ __device__ __forceinline__ void mfma_tile_best(const float* __restrict__ dimg, c
     k_out = take ? ok : bk;
 }
 
-// Single-feature float32 signals: the re-correlation of a group atom's 2W-1 rows on the matrix cores.  The loop keeps
-// (coefficient, atom) per position like the dense form, so a tile's result -- the row's best SCORE and the 32-atom group that holds the
-// first atom attaining it (mfma_tile_score) -- is resolved right away: one chain per lane over that group's atoms (the pinned
-// sequential chain, as the dense form computes it), arg-max with the lowest atom among equals.
-// GS signals per workgroup (1 or 2) share ONE dictionary image: with two, a CU holds two signals and the matrix pipe has the other
-// signal's tiles to run while one is in its serial steps (the 64 KB image and the per-signal state leave no room for two workgroups).
-// LDS: [dictionary image | weights] then per signal [control block][window x 4 | group hints][LocompLds]
+// Single-feature float32 signals: the re-correlation of a group's rows on the matrix cores.  The loop keeps (coefficient, atom) per
+// position like the dense form; mfma_tile_best hands both over for 32 rows at a time, bit-identical to the dense form's chains.
+// GS signals per workgroup (1, 2 or 4) share ONE dictionary image: a CU then holds GS signals, and its matrix pipe has the other
+// signals' tiles to run while one is in its serial steps (the 64 KB image leaves no room for a second workgroup); each signal's four
+// waves meet at their own LDS counter (SoftSync), as in the four-signal greedy loop.
+// LDS: [dictionary image | weights] then per signal [control block][window][LocompLds]
 template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     using R = float;
     // four signals per workgroup: the per-signal state must fit a quarter of what the image leaves -- 256 segment maxima, the Gram
