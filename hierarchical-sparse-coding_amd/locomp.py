@@ -123,7 +123,9 @@ class LoCOMP(ConvolutionalMatchingPursuit):
     def _batch_on_host(self, sequences, D, *args):
         from .modeling import BatchResult
         out = [self._computeCoefficientsHost(np.asarray(s), D, *args) for s in sequences]
-        return BatchResult([o[0] for o in out], np.stack([o[1] for o in out], axis=0), None, None, None, 'locomp_host', None)
+        res = BatchResult([o[0] for o in out], np.stack([o[1] for o in out], axis=0), None, None, None, 'locomp_host', None)
+        self.lastResult = res                 # (no event trace, counters or stop reasons: the host loop keeps none)
+        return res
 
     def computeCoefficients(self, sequence, D, nbNonzeroCoefs=None, toleranceResidualScale=None, toleranceSnr=None,
                             nbBlocks=1, minCoefficients=1e-16, weights=None, stopCondition=None):

@@ -190,6 +190,8 @@ class BatchResult(object):
         self.kernel_ms = kernel_ms
 
     def stop_reasons(self):
+        if self.stats is None:                # (a result of LoCOMP's host loop, which keeps no per-signal counters)
+            return [None] * len(self.coefficients)
         return [_native.STOP_NAMES.get(int(s), int(s)) for s in self.stats[:, _native.STAT_STOP]]
 
 
