@@ -3,7 +3,7 @@ random configurations of tests/test_gpu_fuzz.py: support, coefficients, residual
 are groups of (nearly) dependent atoms -- tiny signals under large dictionaries, a composite atom next to the singletons it is made
 of: the two solvers then pick different least-squares solutions with the same residual, or an entry cancels to
 exactly 0.0 in one of them.      usage: python tools/locomp_soak.py FIRST_SEED LAST_SEED"""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
