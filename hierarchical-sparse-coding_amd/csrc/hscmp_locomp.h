@@ -299,8 +299,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
             const int row = TP * q + lane, t = t0 + row;
             if (lane < TP && row < nrows && t >= 0 && t < T) { G.bc[t] = c; G.bk[t] = k; }      // overlapReplace clipping (utils.py:133-161)
         }
-        if (timed) HSCMP_STAMP(11);                            // tiles
-        if (timed) HSCMP_STAMP(12);                            // rows resolved
+        if (timed) HSCMP_STAMP(11);                            // tiles: (coefficient, atom) of the rows
     }
     // rows p-(W-1) .. p+(W-1) around one atom (:1018-1051)
     template <typename SH>

@@ -30,7 +30,7 @@ print('config', CONFIG, 'level', LEVEL, D.shape, res.variant, 'loop %.1f ms' % r
 sel, atoms = max(v[14], 1), v[15]
 print('workgroup 0, signal 0: %d selections, group size %.2f on average' % (sel, atoms / sel))
 names = {0: 'neighbourhood scan', 1: 'group order', 2: 'right-hand sides + Gram entries', 3: 'Cholesky + substitutions', 4: 'coefficients, subtractions, energies',
-         5: 're-correlation (all of it)', 6: 'segments marked', 10: '  window', 11: '  tiles', 12: '  rows resolved'}
+         5: 're-correlation (all of it)', 6: 'segments marked', 10: '  window', 11: '  tiles'}
 tot = 0.0
 for i in sorted(names):
     if v[i] > 0:
