@@ -75,6 +75,22 @@ def test_locomp_host_loop_with_oracle_hooks(name):
     _check(OracleLoCOMP(), name)
 
 
+def test_refit_choice_of_the_hierarchical_encoder():
+    """LoCOMP() re-fits on the device; the PER-SIGNAL hierarchical entry builds its level coders on the host loop with the
+    reference's own pseudo-inverse (a cascade of levels amplifies last-bit differences between solvers)."""
+    from hsc_amd.modeling import LoCOMP, HierarchicalConvolutionalMatchingPursuit, ConvolutionalMatchingPursuit
+    from hsc_amd import _native
+    assert LoCOMP().refit == 'device' and LoCOMP._method == _native.METHOD_LOCOMP
+    assert getattr(ConvolutionalMatchingPursuit(), '_method', _native.METHOD_CMP) == _native.METHOD_CMP
+    with pytest.raises(AssertionError):
+        LoCOMP(refit='somewhere')
+    D = np.eye(4, 5, dtype=np.float32)
+    coder = HierarchicalConvolutionalMatchingPursuit()._level_coder(D)
+    assert isinstance(coder.approximator, LoCOMP) and coder.approximator.refit == 'host'
+    assert isinstance(HierarchicalConvolutionalMatchingPursuit(method='cmp')._level_coder(D).approximator, ConvolutionalMatchingPursuit)
+    assert _native.STOP_NAMES[_native.STOP_STALLED] == 'stalled' and _native.STOP_NAMES[_native.STOP_GROUP] == 'group'
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', _names())
 def test_locomp_gpu_vs_reference_golden(name):
