@@ -49,6 +49,33 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def _spin(n):
+    t0 = time.perf_counter()
+    x = 0
+    for i in range(n):
+        x += i * i
+    return time.perf_counter() - t0
+
+
+def measured_usable_cores(limit=64):
+    """How many cores the box really gives this job: N spinning processes against one (the GPU boxes show 256 logical cores
+    to os.cpu_count() and to the affinity mask, but schedule about one GPU's share of them)."""
+    import multiprocessing as mp
+    n = min(limit, host_cores())
+    if n <= 1:
+        return 1
+    work = 5000000
+    t1 = min(_spin(work) for _ in range(2))
+    with mp.get_context('fork').Pool(n) as pool:
+        pool.map(_spin, [1000] * n)                      # (workers up before the clock starts)
+        wall = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            pool.map(_spin, [work] * n, chunksize=1)
+            wall.append(time.perf_counter() - t0)
+    return max(1, min(n, int(round(n * t1 / min(wall)))))
+
+
 def cpu_baseline_main(args):
     """Child-process entry (--cpu-baseline-only): never touches the GPU.  Times the NumPy port on one worker per core."""
     import multiprocessing as mp
@@ -58,6 +85,7 @@ def cpu_baseline_main(args):
 
     cfg = json.loads(args.cpu_baseline_only)
     nproc, per_proc = cfg['nproc'], cfg['per_proc']
+    usable = measured_usable_cores()
     npdt = np.float64 if cfg.get('dtype') == 'f64' else np.float32
     D = synth.make_dictionary(cfg['K'], cfg['W'], seed=2, dtype=npdt)
     jobs = []
@@ -75,7 +103,8 @@ def cpu_baseline_main(args):
     nsel = int(sum(o[0] for o in out))
     print(json.dumps({
         'value': nsel / wall, 'unit': 'atom-selections/s', 'cores': nproc, 'kind': 'port',
-        'host_cores': os.cpu_count(), 'usable_cores': host_cores(),
+        'host_cores': os.cpu_count(), 'affinity_cores': host_cores(), 'usable_cores': usable,
+        'usable_cores_note': 'measured: speed-up of min(64, affinity) spinning processes over one',
         'sample': '%d signals (%d processes x %d) of the bench workload, NumPy port of hsc/modeling.py:1053-1186 '
                   '(oracle/numpy_port.py), BLAS threads=1 per process, wall %.1f s' % (nproc * per_proc, nproc, per_proc, wall),
         'per_core': nsel / wall / nproc}))
@@ -158,6 +187,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and out is not None and (out.get('failed') or out.get('config', {}).get('output_check', {}).get('FAILED')):
+        sys.exit(3)                         # the line is out (ranks never hang on it), but a failed output check is a failed run
 
 
 def reduce_over_ranks(ctx, args, elapsed, nsel):
@@ -315,10 +346,13 @@ def bench_cmp(args, ctx):
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction
     # applied by tools/parse_pmc.py; profiles/pmc_summary.json names the build they were collected on); null if the
     # summary does not cover this shape
-    traffic, hbm_fraction, pmc_src = None, None, None
+    traffic, hbm_fraction, pmc_src, pmc_stale = None, None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
-        if cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma') and args.dtype == 'f32':
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from csrc_digest import load_pmc_summary
+        pmc, pmc_stale = load_pmc_summary(os.path.join(ROOT, 'profiles', 'pmc_summary.json'))
+        # (a summary collected on other kernels than this tree's is not reported: traffic = null, pmc_stale = true)
+        if pmc is not None and not pmc_stale and cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma') and args.dtype == 'f32':
             traffic = pmc[dom[3]]['hbm_bytes_per_launch']
             step_bytes = sum(pmc[k]['hbm_bytes_per_launch'] for k in ('prepare_kernel', 'corr_init_mfma_kernel', 'iterate_kernel') if k in pmc)
             hbm_fraction = step_bytes / (elapsed_max / steps) / PEAK_HBM_BYTES
@@ -355,7 +389,7 @@ def bench_cmp(args, ctx):
                      'whole_job_frac': (flop_init + flop_loop) * steps * world / elapsed_max / 1e12 / peak / world,
                      # the HBM side: measured bytes/s of the table-free formulation against 8 TB/s, and the
                      # bandwidth the reference's formulation (one scan of the [T,K] table per selection) would need at this rate
-                     'hbm_fraction': hbm_fraction, 'pmc_source': pmc_src,
+                     'hbm_fraction': hbm_fraction, 'pmc_source': pmc_src, 'pmc_stale': pmc_stale,
                      'table_scan_equiv': {'bytes_per_selection': table_bytes, 'tb_per_s_needed': rate / world * table_bytes / 1e12,
                                           'x_hbm_peak': rate / world * table_bytes / PEAK_HBM_BYTES}},
         'gather': gather,
@@ -365,10 +399,11 @@ def bench_cmp(args, ctx):
         out['config']['output_check']['FAILED'] = True
     # ---- the hierarchical configurations of BASELINE.json at their own sizes, a few steps each (bounded: it must never
     #      cost the headline line): configs[3] with 17 and with the literal 16 level-1 taps, configs[4] at its per-GPU share
-    if world == 1 and not args.no_secondary:
+    if world == 1:
         eng.close()
         del x
         torch.cuda.empty_cache()
+    if world == 1 and not args.no_secondary:
         out['secondary'] = run_secondary(args, ctx)
     if world == 1 and not args.no_cpu_baseline:
         nproc = args.cpu_procs or min(16, host_cores())
@@ -381,6 +416,20 @@ def run_secondary(args, ctx):
     import bench_hsc
     sec = {}
     t_begin = time.perf_counter()
+    # the headline workload in the reference's DEFAULT dtype (float64 inputs, hsc/modeling.py:1053 computes in the input's dtype):
+    # the v_mfma_f64_16x16x4_f64 kernels, a few steps, with their own roofline against the fp64 matrix peak
+    try:
+        a = copy.copy(args)
+        a.dtype, a.steps, a.warmup, a.no_cpu_baseline, a.no_secondary, a.no_transfers, a.profile_steps = 'f64', 3, 1, True, True, True, 2
+        t0 = time.perf_counter()
+        o = bench_cmp(a, ctx)
+        sec['config2_f64'] = {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'], 'dtype': 'f64',
+                              'workload': o['config']['workload'], 'variant': o['config']['variant'], 'output_check': o['config']['output_check'],
+                              'roofline': {k: o['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'kernel_ms', 'all_kernels', 'whole_job_frac')},
+                              'section_wall_s': time.perf_counter() - t0}
+    except (Exception, SystemExit) as ex:
+        sec['config2_f64'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+    ctx['torch'].cuda.empty_cache()
     # (config 4 also with the method the reference's own script runs it with -- learn_mlcsc_dataset.py:108 builds the encoder with
     #  its default, LoCOMP: the device loop of csrc/hscmp_locomp.h)
     for name, config, taps, method in (('config4_17taps', 4, 17, 'cmp'), ('config4_16taps', 4, 16, 'cmp'), ('config5', 5, 17, 'cmp'),
@@ -395,7 +444,7 @@ def run_secondary(args, ctx):
         try:
             sec[name] = bench_hsc.compact(bench_hsc.run(a, ctx))
             sec[name]['section_wall_s'] = time.perf_counter() - t0
-        except BaseException as ex:            # (SystemExit included: reported, never fatal for the headline)
+        except (Exception, SystemExit) as ex:  # (reported, never fatal for the headline; a KeyboardInterrupt still ends the run)
             sec[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         ctx['torch'].cuda.empty_cache()
     return sec

@@ -188,6 +188,15 @@ def run(args, ctx):
     torch.cuda.synchronize(dev)
     elapsed_res = (time.perf_counter() - t1) / nres
     energies_match = bool(np.allclose(energies, np.sum(np.square(residuals.reshape((B, -1))), axis=1), rtol=1e-10, atol=0.0))
+    del residuals
+    # SURVEY 8(d)'s wall clock: the signals cross PCIe into the encoder every step (host array in, no device pointer) and the
+    # per-signal results (coefficient matrices, residual energies) come back -- never `value`
+    nin = max(1, min(3, steps))
+    t2 = time.perf_counter()
+    for _ in range(nin):
+        hcmp.computeCoefficientsBatch(xs, mlds, residuals='energy', **kw)
+    torch.cuda.synchronize(dev)
+    elapsed_in = (time.perf_counter() - t2) / nin
 
     # output check of the timed workload: the multilevel code reconstructs the signals
     snr = 10 * np.log10(np.sum(xs.astype(np.float64) ** 2, axis=1) / np.maximum(energies, 1e-300))
@@ -204,7 +213,32 @@ def run(args, ctx):
         check['FAILED'] = True
 
     import bench as _b
+    # ---- gather of the per-signal multilevel results over the ranks (north_star: "gather of per-signal results only"; configs[4] is
+    #      "batch sharded 8 GPU"): event records (hsc/dataset.py:798-811) + float64 values + counts + residual energies, rebuilt
+    #      into per-level matrices on every rank.  After the timed region, reported beside the metric.
+    gather = None
+    if world > 1:
+        try:
+            from hsc_amd import parallel
+            coefs_g, energies_g, _, events_g = hcmp.computeCoefficientsBatch(xs, mlds, deviceInput=x_dev.data_ptr(), residuals='energy',
+                                                                             returnEvents=True, **kw)
+            vals = [parallel._values_of_events(c, e) for c, e in zip(coefs_g, events_g)]
+            fence()
+            t3 = time.perf_counter()
+            g = parallel.gather_hierarchical(events_g, energies_g, vals, device=dev if args.backend == 'nccl' else None)
+            if args.backend == 'nccl':
+                torch.cuda.synchronize(dev)
+            t_coll = time.perf_counter() - t3
+            counts = [int(mlds.getRawDictionary(l).shape[0]) for l in range(nlev)]
+            mats = [parallel.events_to_level_matrices(e, counts, T, g['values64'][i]) for i, e in enumerate(g['events'])]
+            mine = all((mats[rank * B + b][l] != coefs_g[b][l]).nnz == 0 for b in range(0, B, max(1, B // 8)) for l in range(nlev))
+            gather = {'ms': 1e3 * t_coll, 'rebuild_ms': 1e3 * (time.perf_counter() - t3 - t_coll), 'bytes_per_signal': g['bytes_per_signal'],
+                      'bytes_this_rank': g['bytes_total'], 'signals': len(g['events']), 'own_shard_matches_encoder': bool(mine)}
+            del coefs_g, events_g, vals, g, mats
+        except Exception as ex:            # (reported beside the metric, never part of it)
+            gather = {'error': '%s: %s' % (type(ex).__name__, ex)}
     elapsed_max, nsel_total = _b.reduce_over_ranks(ctx, args, elapsed, nsel_local)
+    elapsed_in_max, _ = _b.reduce_over_ranks(ctx, args, elapsed_in, 0)
     if rank != 0:
         return None
     kernel_ms = float(sum(sum(tm['kernel_ms'][:3]) for tm in timings))
@@ -224,11 +258,12 @@ def run(args, ctx):
         else:
             e.update(level_roofline(Dl, T, B, tm, nbBlocks=kw['nbBlocks']))
         levels.append(e)
-    pmc = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary_hsc%d.json' % config)))
-    except Exception:
-        pass
+    # PMC traffic figures only from a summary collected on THIS tree's kernels (tools/csrc_digest.py stamps it)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from csrc_digest import load_pmc_summary
+    pmc, pmc_stale = load_pmc_summary(os.path.join(ROOT, 'profiles', 'pmc_summary_hsc%d%s.json' % (config, '_locomp' if getattr(args, 'method', 'cmp') == 'locomp' else '')))
+    if pmc_stale:
+        pmc = None
     dom = max(levels, key=lambda e: e['loop_ms'] + e['init_ms'])
     l0 = levels[0]
     out = {
@@ -241,7 +276,11 @@ def run(args, ctx):
         'roofline': {'bound': 'mfma', 'kernel': 'level-0 greedy loop (iterate_kernel, blocked selection)', 'achieved': l0['loop_tflops'],
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': l0['loop_frac'], 'kernel_ms': l0['loop_ms'],
                      'traffic': (pmc or {}).get('level0_loop_hbm_bytes_per_launch'), 'dominant_level': dom['level'],
-                     'levels': levels, 'pmc': pmc},
+                     'levels': levels, 'pmc': pmc, 'pmc_stale': pmc_stale},
+        'value_incl_transfers': nsel_total / elapsed_in_max,
+        'transfers': {'ms_per_step': 1e3 * elapsed_in_max, 'h2d_bytes_per_step': int(xs.nbytes),
+                      'note': 'the same step fed from a (pageable) host array: H2D of the signals, the encode, D2H of the coefficient matrices and residual energies'},
+        'gather': gather,
         'value_incl_residual_transfer': nsel_local * world / elapsed_res,
         'residual_transfer': {'ms_per_step': 1e3 * elapsed_res, 'd2h_bytes_per_step': int(B * T * 8),
                               'note': 'the same step with the float64 residual samples of every signal fetched to the host (this rank)'},
@@ -258,6 +297,9 @@ def run(args, ctx):
         except Exception as ex:
             out['cpu_baseline'] = {'error': str(ex)}
     hcmp.close()
+    if check.get('FAILED'):
+        out['value'] = None                 # a broken encode must not leave a valid-looking throughput figure behind
+        out['failed'] = 'output_check'
     return out
 
 
@@ -265,7 +307,7 @@ def compact(out):
     """The figures of a hierarchical bench line that bench.py's default run carries in its `secondary` object."""
     if out is None:
         return None
-    keep = {k: out[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'value_incl_residual_transfer')}
+    keep = {k: out[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'value_incl_transfers', 'value_incl_residual_transfer')}
     keep['workload'] = out['config']['workload']
     keep['method'] = out['config'].get('method', 'cmp')
     keep['signals_per_gpu'] = out['config']['signals_per_gpu']

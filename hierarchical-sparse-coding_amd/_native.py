@@ -26,7 +26,7 @@ METHOD_CMP, METHOD_LOCOMP = 0, 1
 EXPORTS = ['hscmp_version', 'hscmp_create', 'hscmp_destroy', 'hscmp_last_error', 'hscmp_set_stream', 'hscmp_set_method',
            'hscmp_synchronize', 'hscmp_set_dictionary', 'hscmp_convolve1d', 'hscmp_select_best_atoms',
            'hscmp_update_inner_products', 'hscmp_table_open', 'hscmp_table_select', 'hscmp_table_update', 'hscmp_table_read', 'hscmp_assign_windows', 'hscmp_host_overlap_add', 'hscmp_host_slots_to_csc', 'hscmp_hierarchy_epilogue', 'hscmp_encode_batch',
-           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_stop_signal', 'hscmp_fetch_events',
+           'hscmp_encode_batch_device', 'hscmp_encode_batch_from_level', 'hscmp_continue', 'hscmp_grow_events', 'hscmp_mem_info', 'hscmp_copy_from_device', 'hscmp_stop_signal', 'hscmp_fetch_events',
            'hscmp_fetch_stats', 'hscmp_fetch_residual', 'hscmp_fetch_energies', 'hscmp_fetch_slots',
            'hscmp_get_device_view', 'hscmp_last_kernel_ms', 'hscmp_last_variant']
 
@@ -108,6 +108,7 @@ def load_library():
     lib.hscmp_continue.argtypes = [vp, ci]
     lib.hscmp_grow_events.argtypes = [vp, ci]
     lib.hscmp_mem_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.hscmp_copy_from_device.argtypes = [vp, vp, ctypes.c_uint64, vp]
     lib.hscmp_stop_signal.argtypes = [vp, ci]
     lib.hscmp_fetch_events.argtypes = [vp, vp, vp, vp]
     lib.hscmp_fetch_stats.argtypes = [vp, vp]
@@ -459,6 +460,12 @@ class Engine(object):
         f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self._lib.hscmp_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)), 'hscmp_mem_info')
         return int(f.value), int(t.value)
+
+    def copy_from_device(self, dev_ptr, shape, dtype):
+        """Device memory at `dev_ptr` (this engine's GPU) as a new host array of the given shape / dtype."""
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.hscmp_copy_from_device(self._h, ctypes.c_void_p(int(dev_ptr)), ctypes.c_uint64(out.nbytes), _ptr(out)), 'hscmp_copy_from_device')
+        return out
 
     def stop_signal(self, b):
         self._check(self._lib.hscmp_stop_signal(self._h, int(b)), 'hscmp_stop_signal')

@@ -1058,6 +1058,17 @@ extern "C" int hscmp_mem_info(hscmp_ctx* ctx, uint64_t* free_bytes, uint64_t* to
 
 extern "C" const char* hscmp_last_variant(hscmp_ctx* ctx) { return ctx ? ctx->variant.c_str() : ""; }
 
+extern "C" int hscmp_copy_from_device(hscmp_ctx* ctx, const void* src_dev, uint64_t nbytes, void* dst_host)
+{
+    if (!ctx) return fail(nullptr, HSCMP_ERR_INVALID, "hscmp_copy_from_device: ctx is NULL");
+    if (!src_dev || !dst_host) return fail(ctx, HSCMP_ERR_INVALID, "hscmp_copy_from_device: NULL argument");
+    if (nbytes == 0) return HSCMP_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HSCMP_OK;
+}
+
 // modeling.py:149-188 convolve1d on the GPU: full table out [Tout][K]
 template <typename R> static void launch_convolve(hscmp_ctx* ctx, const R* dx, int T, int same, int Tout, R* dout)
 {
@@ -1466,11 +1477,9 @@ template <typename R> static int run_table_open(hscmp_ctx* ctx, const void* x, i
     if ((rc = epi_buffer(ctx, kArenaTabRes, (size_t)T * F * sizeof(R))) != HSCMP_OK) return rc;
     if ((rc = epi_buffer(ctx, kArenaTable, (size_t)T * K * sizeof(R))) != HSCMP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_epi[kArenaTabRes], x, (size_t)T * F * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
-    {   // the caller's buffer may be reused as soon as this returns (as hscmp_table_update promises): wait for the upload
-        hipEvent_t up = ctx->ev[0];
-        HIP_TRY(ctx, hipEventRecord(up, ctx->stream));
-        HIP_TRY(ctx, hipEventSynchronize(up));
-    }
+    // the caller's buffer may be reused as soon as this returns (as hscmp_table_update promises): wait for the upload (not through
+    // ev[]: those are the batch-timing events hscmp_last_kernel_ms reads)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (table_rows_are_sparse(ctx)) launch_table_rows_sparse<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 0, T, -1, (R*)ctx->d_epi[kArenaTable]);
     else launch_convolve<R>(ctx, (const R*)ctx->d_epi[kArenaTabRes], T, 1, T, (R*)ctx->d_epi[kArenaTable]);
     HIP_TRY(ctx, hipGetLastError());

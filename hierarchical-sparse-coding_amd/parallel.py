@@ -37,7 +37,10 @@ def _comm_device(device=None):
     if dist.is_initialized() and dist.get_backend() == 'nccl':
         if device is None:
             device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
-        torch.cuda.set_device(device)
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:           # ('cuda' without an index: the current device)
+            device = torch.device('cuda', torch.cuda.current_device())
+        torch.cuda.set_device(device)       # (RCCL binds a communicator to the current device: it stays current afterwards)
         return device
     return torch.device('cpu')
 
@@ -124,6 +127,9 @@ def gather_results(source, device=None, residuals=None):
     """
     import torch
     dist = _dist()
+    if device is None and not isinstance(source, dict) and getattr(source, 'device', None) is not None \
+            and dist.is_initialized() and dist.get_backend() == 'nccl':
+        device = torch.device('cuda', int(source.device))       # the engine's own GPU: its raw pointers are only valid there
     dev = _comm_device(device)
     if isinstance(source, dict):
         as_t = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev)
@@ -231,3 +237,136 @@ def encode_sharded(sequences_shard, D, encode_fn=None, gather=True, residuals=Fa
         out['events'].append((g['ev_t'][i, :n].copy(), g['ev_k'][i, :n].copy(), g['ev_c'][i, :n].copy()))
         out['coefficients'].append(events_to_coefficients(g['ev_t'][i], g['ev_k'][i], g['ev_c'][i], n, (T, K), minCoefficients))
     return out
+
+
+# ---- the hierarchical encoder (hsc/modeling.py:1636-1643): gather of the per-signal multilevel results ------------------------
+# What a rank holds per signal after HierarchicalConvolutionalMatchingPursuit.computeCoefficientsBatch(returnEvents=True): the event
+# records of hsc/dataset.py:798-811 -- (time int32, level int32, index int32, coefficient float32), 16 bytes each, sorted by time --
+# the float64 coefficient behind every record (the reference's matrices are float64, :1074; its wire format rounds to float32) and the
+# residual energy.  They travel as ONE ragged buffer per rank (the records of its signals back to back, padded to the longest rank
+# only) plus the per-signal counts: no [signals x longest list] padding.
+
+def _pack_records(events):
+    """Event records of this rank's signals -> (int32 [n, 4] with the float32 coefficient bit-cast, counts int64 [b])."""
+    counts = np.array([len(e) for e in events], dtype=np.int64)
+    rec = np.zeros((int(counts.sum()), 4), dtype=np.int32)
+    o = 0
+    for e in events:
+        n = len(e)
+        rec[o:o + n, 0] = e['f0']; rec[o:o + n, 1] = e['f1']; rec[o:o + n, 2] = e['f2']
+        rec[o:o + n, 3] = np.ascontiguousarray(e['f3'], dtype=np.float32).view(np.int32)
+        o += n
+    return rec, counts
+
+
+def _unpack_records(rec):
+    from .dataset import EVENT_DTYPE
+    e = np.zeros((rec.shape[0],), dtype=EVENT_DTYPE)
+    e['f0'] = rec[:, 0]; e['f1'] = rec[:, 1]; e['f2'] = rec[:, 2]
+    e['f3'] = np.ascontiguousarray(rec[:, 3]).view(np.float32)
+    return e
+
+
+def events_to_level_matrices(events, counts, T, values64=None):
+    """Per-level csc_matrix [T, count] (float64) of one signal from its event records -- convertEventsToSparseMatrices
+    (hsc/dataset.py:813-824) with the float64 values when they came along (`values64`), else the records' float32 ones."""
+    import scipy.sparse
+    v = np.asarray(events['f3'], dtype=np.float64) if values64 is None else np.asarray(values64, dtype=np.float64)
+    t = np.asarray(events['f0'], dtype=np.int64); l = np.asarray(events['f1']); i = np.asarray(events['f2'], dtype=np.int64)
+    out = []
+    for level, count in enumerate(counts):
+        m = l == level
+        out.append(scipy.sparse.coo_matrix((v[m], (t[m], i[m])), shape=(int(T), int(count))).tocsc())
+    return out
+
+
+def gather_hierarchical(events, energies, values64=None, device=None):
+    """All ranks' multilevel per-signal results, in rank order, on every rank.
+
+    events   : list (this rank's signals) of event record arrays (hsc_amd.dataset.EVENT_DTYPE)
+    energies : float64 [b] residual energies          values64 : optional list of float64 arrays, one value per record
+    Returns {'events': list over ALL signals, 'values64': list or None, 'energies': float64 [B_total], 'counts': int64 [B_total],
+             'bytes_per_signal': mean payload of the collectives per signal, 'bytes_total': payload of this rank}"""
+    import torch
+    dist = _dist()
+    dev = _comm_device(device)
+    rec, counts = _pack_records(events)
+    en = np.ascontiguousarray(energies, dtype=np.float64).reshape((-1,))
+    assert en.shape[0] == counts.shape[0]
+    vals = None if values64 is None else (np.concatenate([np.asarray(v, dtype=np.float64) for v in values64]) if len(values64) else np.zeros((0,)))
+    assert vals is None or vals.shape[0] == rec.shape[0]
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    collect = _collectives_on()
+    b, n = int(counts.shape[0]), int(rec.shape[0])
+    meta = torch.tensor([b, n], dtype=torch.int64, device=dev)
+    if collect:
+        metas = torch.empty((world * 2,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta)
+        metas = metas.reshape((world, 2)).cpu().numpy()
+    else:
+        metas = meta[None].cpu().numpy()
+    bpad, npad = int(metas[:, 0].max()), int(metas[:, 1].max())
+
+    def gather(a, pad, sizes):
+        x = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        if x.shape[0] < pad:
+            x = torch.cat([x, torch.zeros((pad - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)], dim=0)
+        if not collect:
+            return a, int(x.numel() * x.element_size())
+        out = torch.empty((world * pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        out = out.cpu().numpy().reshape((world, pad) + tuple(x.shape[1:]))
+        return np.concatenate([out[r, :int(sizes[r])] for r in range(world)], axis=0), int(x.numel() * x.element_size())
+
+    payload = 0
+    g_counts, nb = gather(counts, bpad, metas[:, 0]); payload += nb
+    g_en, nb = gather(en, bpad, metas[:, 0]); payload += nb
+    g_rec, nb = gather(rec, npad, metas[:, 1]); payload += nb
+    g_vals = None
+    if vals is not None:
+        g_vals, nb = gather(vals, npad, metas[:, 1]); payload += nb
+    ev_all = _unpack_records(g_rec)
+    starts = np.concatenate(([0], np.cumsum(g_counts)))
+    out_events = [ev_all[int(starts[i]):int(starts[i + 1])] for i in range(len(g_counts))]
+    out_vals = None if g_vals is None else [g_vals[int(starts[i]):int(starts[i + 1])] for i in range(len(g_counts))]
+    return dict(events=out_events, values64=out_vals, energies=g_en, counts=g_counts, bytes_total=payload,
+                bytes_per_signal=payload / max(1, bpad))
+
+
+def _values_of_events(coefficients, events):
+    """The float64 value of every event record, from the per-level matrices the records were made of."""
+    mats = [c.tocsr() for c in coefficients]
+    out = np.zeros((len(events),), dtype=np.float64)
+    l = np.asarray(events['f1'])
+    for level, m in enumerate(mats):
+        sel = np.where(l == level)[0]
+        if len(sel):
+            out[sel] = np.asarray(m[np.asarray(events['f0'])[sel], np.asarray(events['f2'])[sel]]).reshape((-1,))
+    return out
+
+
+def encode_sharded_hierarchical(sequences_shard, multilevelDict, encode_fn=None, gather=True, exact=True, method='cmp', **kwargs):
+    """The hierarchical encoder on this rank's shard, then (optionally) every rank's per-signal multilevel results on every rank.
+
+    encode_fn : callable(sequences, multilevelDict, **kwargs) -> (per-signal lists of per-level matrices, residual energies [b],
+                per-signal event records); defaults to HierarchicalConvolutionalMatchingPursuit(method).computeCoefficientsBatch on
+                cuda:LOCAL_RANK with the device epilogue (events and energies come out of hscmp_hierarchy_epilogue)
+    exact     : the float64 coefficients travel beside the float32 records, so the rebuilt matrices equal the encoder's bit for bit
+    Returns {'coefficients': per signal a list of per-level csc_matrix, 'events', 'energies', 'bytes_per_signal', 'bytes_total'}."""
+    if encode_fn is None:
+        import os
+        from .hierarchical import HierarchicalConvolutionalMatchingPursuit
+        hcmp = HierarchicalConvolutionalMatchingPursuit(method=method, device=int(os.environ.get('LOCAL_RANK', '0')))
+
+        def encode_fn(xs, mld, **kw):
+            coefs, energies, _, events = hcmp.computeCoefficientsBatch(xs, mld, returnEvents=True, residuals='energy', **kw)
+            return coefs, energies, events
+    coefs, energies, events = encode_fn(sequences_shard, multilevelDict, **kwargs)
+    T = sequences_shard.shape[1]
+    counts = [int(multilevelDict.getRawDictionary(l).shape[0]) for l in range(multilevelDict.getNbLevels())]
+    if not gather or not _collectives_on():
+        return dict(coefficients=coefs, events=events, energies=np.asarray(energies, dtype=np.float64), bytes_per_signal=0, bytes_total=0)
+    vals = [_values_of_events(c, e) for c, e in zip(coefs, events)] if exact else None
+    g = gather_hierarchical(events, energies, vals)
+    mats = [events_to_level_matrices(e, counts, T, None if g['values64'] is None else g['values64'][i]) for i, e in enumerate(g['events'])]
+    return dict(coefficients=mats, events=g['events'], energies=g['energies'], bytes_per_signal=g['bytes_per_signal'], bytes_total=g['bytes_total'])

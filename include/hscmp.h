@@ -268,6 +268,11 @@ int hscmp_last_kernel_ms(hscmp_ctx* ctx, float* out4);
  * hierarchical encoder keeps a dense float64 residual [T][K_prev] per signal on the device). */
 int hscmp_mem_info(hscmp_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* Copy `nbytes` of device memory of the context's GPU to the host, ordered behind the context's stream.  For callers that handed
+ * the batch over as a device pointer (hscmp_encode_batch_device) and need single signals back on the host -- the per-signal host
+ * loop that takes over a signal the batch path gave up on (hsc/modeling.py:1267 with a stopCondition, ...). */
+int hscmp_copy_from_device(hscmp_ctx* ctx, const void* src_dev, uint64_t nbytes, void* dst_host);
+
 /* Name of the kernel variant the last encode dispatched ("mfma_f32", "generic_f64", ...). */
 const char* hscmp_last_variant(hscmp_ctx* ctx);
 

@@ -41,5 +41,20 @@ assert np.array_equal(g3['ev_t'], g['ev_t'])
 # the device views really are views: no copy was made of the event buffers
 st, en, et, ek, ec = parallel._engine_result_tensors(eng, dev)
 assert et.is_cuda and et.data_ptr() == eng.device_view().ev_t
+# the hierarchical encoder's gather (BASELINE configs[4]): the real GPU batch entry with the device epilogue, its event records,
+# float64 values, counts and residual energies through RCCL; the rebuilt per-level matrices equal the encoder's own
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_parallel import _hier_inputs
+from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+mld, xs, kw = _hier_inputs()
+hc = HierarchicalConvolutionalMatchingPursuit(method='cmp', device=0)
+coefs, energies, _, events = hc.computeCoefficientsBatch(xs, mld, returnEvents=True, residuals='energy', **kw)
+out = parallel.encode_sharded_hierarchical(xs, mld, method='cmp', **kw)
+assert out['bytes_total'] > 0 and np.array_equal(out['energies'], energies)
+for b in range(xs.shape[0]):
+    assert np.array_equal(out['events'][b], events[b])
+    for l in range(mld.getNbLevels()):
+        assert (out['coefficients'][b][l] != coefs[b][l]).nnz == 0 and out['coefficients'][b][l].nnz == coefs[b][l].nnz
+hc.close()
 dist.destroy_process_group()
 print('NCCL-CHILD-OK')

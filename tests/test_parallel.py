@@ -138,3 +138,94 @@ def test_gather_from_device_buffers_under_nccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     res = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'NCCL-CHILD-OK' in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
+
+
+# ---- the hierarchical encoder across ranks (BASELINE configs[4]: "3-level HSC ... batch sharded 8 GPU") -------------------------
+
+def _oracle_level_coder(D):
+    from oracle import hsc_oracle as orc
+
+    class Coder(object):
+        def encode(self, X, **kw):
+            c, r, _ = orc.cmp_encode(np.asarray(X), D, **kw)
+            return c, r
+    return Coder()
+
+
+def _hier_inputs():
+    """The small 3-level dictionary of tests/golden/hsc_small.npz and seven related signals."""
+    import golden_util as gu
+    from hsc_amd.dataset import MultilevelDictionary
+    z = gu.load('hsc_small.npz')
+    mld = MultilevelDictionary.fromRawDictionaries([z['raw0'], z['raw1'], z['raw2']], [int(s) for s in z['scales']]).withSingletonBases()
+    rs = np.random.RandomState(12)
+    x = z['x']
+    xs = np.stack([x, 0.5 * x, x[::-1].copy(), np.roll(x, 17), x + 0.02 * rs.standard_normal(x.shape).astype(x.dtype),
+                   np.roll(x[::-1], 5).copy(), 2.0 * x]).astype(x.dtype)
+    return mld, xs, dict(toleranceSnr=[15.0, 20.0, 25.0], nbBlocks=4, singletonWeight=0.9)
+
+
+def _oracle_hier_encode(xs, mld, **kw):
+    """The host logic of the hierarchical encoder (hsc/modeling.py:1427-1654) on the CPU oracle as level coder: the stand-in for
+    the GPU batch entry in the CPU tests -- (per-signal level matrices, residual energies, event records)."""
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    from hsc_amd.dataset import convertSparseMatricesToEvents
+    h = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    h._level_coder = _oracle_level_coder
+    coefs, energies, events = [], [], []
+    for x in xs:
+        c, r = h.computeCoefficients(x, mld, **kw)
+        coefs.append(c); energies.append(float(np.sum(np.square(np.asarray(r, dtype=np.float64)))))
+        events.append(convertSparseMatricesToEvents(c))
+    return coefs, np.array(energies), events
+
+
+def _hier_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import pickle
+    import torch.distributed as dist
+    from hsc_amd.parallel import shard_bounds, encode_sharded_hierarchical
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mld, xs, kw = _hier_inputs()
+        first, last = shard_bounds(xs.shape[0], world, rank)
+        out = encode_sharded_hierarchical(xs[first:last], mld, encode_fn=_oracle_hier_encode, **kw)
+        lean = encode_sharded_hierarchical(xs[first:last], mld, encode_fn=_oracle_hier_encode, exact=False, **kw)
+        assert lean['bytes_total'] < out['bytes_total']
+        if rank == 1:                               # (every rank holds every signal's results: check the one that is not rank 0)
+            with open(os.path.join(out_dir, 'hier.pkl'), 'wb') as f:
+                pickle.dump(dict(out=out, lean_coefficients=lean['coefficients']), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_hierarchical_gather(tmp_path):
+    """Two gloo ranks shard seven signals, run the 3-level encode on their shards and gather events (the reference's wire format,
+    hsc/dataset.py:798-811), float64 values, counts and residual energies: every signal's per-level matrices, events and energy equal
+    the single-process result."""
+    import pickle
+    import socket
+    import golden_util as gu
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hier_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    with open(os.path.join(str(tmp_path), 'hier.pkl'), 'rb') as f:
+        got = pickle.load(f)
+    mld, xs, kw = _hier_inputs()
+    coefs, energies, events = _oracle_hier_encode(xs, mld, **kw)
+    out = got['out']
+    assert len(out['coefficients']) == xs.shape[0] and np.array_equal(out['energies'], energies)
+    for b in range(xs.shape[0]):
+        assert np.array_equal(out['events'][b], events[b]), b
+        for l in range(3):
+            a, e = gu.csc_triplets(out['coefficients'][b][l]), gu.csc_triplets(coefs[b][l])
+            assert out['coefficients'][b][l].shape == coefs[b][l].shape
+            assert all(np.array_equal(u, v) for u, v in zip(a, e)), (b, l)           # float64 values travelled: bit for bit
+            f32 = gu.csc_triplets(got['lean_coefficients'][b][l])
+            assert np.array_equal(f32[0], e[0]) and np.array_equal(f32[2], e[2].astype(np.float32).astype(np.float64)), (b, l)
+    # the payload is per-signal results only: 24 bytes per coefficient (16-byte record + float64 value) + 16 bytes
+    nev = max(sum(len(events[b]) for b in range(0, 4)), sum(len(events[b]) for b in range(4, 7)))
+    assert 0 < out['bytes_per_signal'] <= 16384 and out['bytes_total'] == 24 * nev + 16 * 4

@@ -12,7 +12,9 @@ Per kernel (averages over its launches): every counter found, the launch duratio
   write_bytes = WRITE_SIZE x 1024
   hbm_bytes_per_launch = read_bytes + write_bytes
   mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
-FETCH_SIZE and WRITE_SIZE come from separate passes, never combined with a trace domain other than --kernel-trace."""
+FETCH_SIZE and WRITE_SIZE come from separate passes, never combined with a trace domain other than --kernel-trace.
+`_csrc_sha256` (tools/csrc_digest.py) stamps the summary with the sources it was collected on: the benches drop the traffic figures
+of a summary whose stamp differs from the tree they run from."""
 import collections
 import csv
 import glob
@@ -20,6 +22,9 @@ import json
 import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_digest import csrc_digest  # noqa: E402
 
 
 def short(name):
@@ -51,7 +56,7 @@ def main():
                 if r['Dispatch_Id'] not in seen:
                     seen.add(r['Dispatch_Id'])
                     dur[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-    out = {'_source': source}
+    out = {'_source': source, '_csrc_sha256': csrc_digest()}
     for k, cs in agg.items():
         d = {c: sum(v) / len(v) for c, v in cs.items()}
         d['launches_seen'] = len(dur[k])
