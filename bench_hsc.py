@@ -247,7 +247,7 @@ def run(args, ctx):
     levels = []
     for l, tm in enumerate(timings):
         Dl = mlds.getRawDictionary(l)
-        e = {'level': l, 'dictionary': list(Dl.shape), 'variant': tm['variant'], 'selections': tm['selections'],
+        e = {'level': l, 'dictionary': list(Dl.shape), 'variant': tm['variant'], 'selections': tm['selections'], 'stop_reasons': tm.get('stops'),
              'prepare_ms': tm['kernel_ms'][0], 'init_ms': tm['kernel_ms'][1], 'loop_ms': tm['kernel_ms'][2],
              'selections_per_s': tm['selections'] / (1e-3 * max(sum(tm['kernel_ms'][:3]), 1e-9))}
         if l == 0:

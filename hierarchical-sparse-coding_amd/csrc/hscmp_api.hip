@@ -365,6 +365,8 @@ static int make_params_g(hscmp_ctx* ctx, int K, int W, int F, int B, int T, cons
     if (const char* v = getenv("HSCMP_SLOT_HASH_MIN")) P.hash_min = std::max(0, atoi(v));
     if (ctx && ctx->method == HSCMP_METHOD_LOCOMP) P.hash_min = INT_MAX;        // (its atom body scans the slot list for the neighbourhood anyway)
     P.max_rounds = p->max_rounds;
+    P.lg_cap = kLocompGroupCap;
+    if (const char* v = getenv("HSCMP_LOCOMP_GROUP_CAP")) P.lg_cap = std::min(4096, std::max(2, atoi(v)));
     *out = P;
     return HSCMP_OK;
 }
@@ -425,7 +427,7 @@ static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, s
         {(void**)&ctx->d_hkey, &ctx->cap_hkey, B * ((size_t)P.hmask + 1) * sizeof(unsigned long long)},
         {(void**)&ctx->d_hval, &ctx->cap_hval, B * ((size_t)P.hmask + 1) * sizeof(int)},
         {(void**)&ctx->d_head, &ctx->cap_head, P.blocked ? B * T * sizeof(int) : 0},
-        {(void**)&ctx->d_lgram, &ctx->cap_lgram, ctx->method == HSCMP_METHOD_LOCOMP ? B * (size_t)kLgramDoubles * sizeof(double) : 0},
+        {(void**)&ctx->d_lgram, &ctx->cap_lgram, ctx->method == HSCMP_METHOD_LOCOMP ? B * lgram_doubles(P.lg_cap) * sizeof(double) : 0},
     };
     bool stream_idle = false;
     for (const BufCap& b : bufs) {

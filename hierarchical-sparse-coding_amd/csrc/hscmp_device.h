@@ -196,7 +196,13 @@ struct DevParams {
     unsigned hmask;     // slots of the per-signal (t,k) -> coefficient-slot hash table, minus one (power of two >= 2*cap)
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
+    int lg_cap;         // LoCOMP: atoms of the largest group the signal's global scratch holds (lgram_doubles; larger: STOP_GROUP)
 };
+
+// LoCOMP: doubles of global scratch per signal for a group of up to `cap` atoms (hscmp_locomp.h, GroupGlobal): two packed triangles
+// (Gram matrix / factor, S of the minimum-norm completion), four double vectors, six int lists
+constexpr int kLocompGroupCap = 512;
+__host__ __device__ inline size_t lgram_doubles(int cap) { return (size_t)cap * ((size_t)cap + 1) + 4 * (size_t)cap + 3 * (size_t)cap; }
 
 // table size of the slot hash: load factor <= 1/2 whatever the event list holds
 inline unsigned slot_hash_mask(int cap)
@@ -272,9 +278,8 @@ template <typename R> struct State {
     R* energy;          // [B][2]: signal, residual
     unsigned long long* edge;   // [B][kEdgeWords]: edge rows re-correlated at least once + the stale-sample record (score-only policies)
     int* head;          // [B][T] round-parallel loop: most recent coefficient slot at position t (-1: none), chained through hval
-    double* lgram;      // [B][kLgramDoubles] LoCOMP: packed Gram matrix of a group that outgrows its LDS copy (nullptr: other methods)
+    double* lgram;      // [B][lgram_doubles(lg_cap)] LoCOMP: what a group keeps beyond its LDS copy (nullptr: other methods)
 };
-constexpr int kLgramDoubles = 128 * 129 / 2;   // (kLocompMax atoms, hscmp_locomp.h)
 
 __device__ __forceinline__ float rabs(float v) { return fabsf(v); }
 __device__ __forceinline__ double rabs(double v) { return fabs(v); }

@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
     G.head = S.head;
-    G.lgram = S.lgram ? S.lgram + (int64_t)b * kLgramDoubles : nullptr;
+    G.lgram = S.lgram ? S.lgram + (int64_t)b * (int64_t)lgram_doubles(P.lg_cap) : nullptr;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
         g_blk[3 * b + 0] = wall_clock64();

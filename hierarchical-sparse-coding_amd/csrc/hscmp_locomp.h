@@ -24,14 +24,17 @@
 
 namespace hscmp {
 
-constexpr int kLocompMax = 128;       // atoms of a group, the selected one included (larger: STOP_GROUP, the host loop takes over)
+constexpr int kLocompMax = 128;       // atoms of a group whose LISTS stay in LDS, the selected one included (larger groups: the signal's global
+                                      // scratch, up to DevParams::lg_cap atoms; beyond that STOP_GROUP and the host loop takes over)
 constexpr int kLocompLds = 64;        // ... whose Gram matrix stays in LDS (larger groups: the signal's global scratch, Sig::lgram)
-// Nearly dependent atoms in a group (a Cholesky pivot that all but vanishes against its diagonal entry): the re-fit is solved in
-// float64 whatever the dictionary's dtype, an atom the others already span keeps coefficient 0.  The reference's pseudo-inverse is
-// an SVD in the DICTIONARY's dtype with a cut-off of 1e-15: on such a group its float32 result is round-off amplified by the
-// condition number, which no other solver reproduces -- there the two agree on the residual they leave, not coefficient by
-// coefficient (the hierarchical per-signal entry therefore keeps the reference's own LAPACK call on the host).
-constexpr double kLocompDead = 1e-12;
+// Dependent atoms in a group (a Cholesky pivot that vanishes against its own diagonal entry): the group is rank deficient and the
+// re-fit is the MINIMUM-NORM least-squares solution, which is what the reference's np.linalg.pinv (:1326) returns once its SVD has
+// cut the vanishing singular value (locomp_atom: minimum-norm completion).  The re-fit runs in float64 whatever the dictionary's
+// dtype.  The reference's cut-off is 1e-15 of the largest singular value IN THE DICTIONARY'S DTYPE: an exact dependency (a composite
+// atom beside all of its singletons, a group that fills its signal) comes out of LAPACK as an exact 0 or ~1e-17 and is cut in both
+// dtypes; a float32 group whose smallest singular value is mere round-off (1e-8 .. 1e-7 of the largest) is NOT cut there and the
+// reference's coefficients are that round-off amplified by 1e7 (measured: DESIGN.md section 7e) -- nothing reproduces those.
+constexpr double kLocompRankTol = 1e-13;
 
 template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
@@ -328,6 +331,110 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// ---- a group beyond its LDS copy: the signal's scratch in global memory (Sig::lgram, lgram_doubles(cap) doubles per signal) ----
+// [Gram matrix / its factor: lower triangle, cap (cap + 1) / 2][S = L^T L of the minimum-norm completion: the same][b][diag][w][a]
+// [t][k][si][ut][uk][usi] (ints).  All accesses are agent-scope atomics (L2), as the slot hash table's: whatever a wave's vector
+// cache holds, a value written before a barrier is the value read behind it.
+struct GroupGlobal {
+    double* gram; double* s; double* b; double* diag; double* w; double* a;
+    int* t; int* k; int* si; int* ut; int* uk; int* usi;
+};
+__device__ __forceinline__ GroupGlobal group_global(double* base, int cap)
+{
+    GroupGlobal g;
+    const int64_t tri = (int64_t)cap * (cap + 1) / 2;
+    g.gram = base; g.s = base + tri; g.b = g.s + tri; g.diag = g.b + cap; g.w = g.diag + cap; g.a = g.w + cap;
+    int* ib = reinterpret_cast<int*>(g.a + cap);
+    g.t = ib; g.k = ib + cap; g.si = ib + 2 * cap; g.ut = ib + 3 * cap; g.uk = ib + 4 * cap; g.usi = ib + 5 * cap;
+    return g;
+}
+template <typename T> __device__ __forceinline__ T gld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void gst(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// arg-max of (value, index) over the lanes of a wave, the lowest index among equal values; the result in every lane
+__device__ __forceinline__ void wave_argmax_f64(double& v, int& i)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m);
+        const int oi = __shfl_xor(i, m);
+        const bool take = ov > v || (ov == v && oi < i);
+        v = take ? ov : v; i = take ? oi : i;
+    }
+}
+__device__ __forceinline__ void wave_argmax_f64(double& v, int& i, int& aux)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m);
+        const int oi = __shfl_xor(i, m), oa = __shfl_xor(aux, m);
+        const bool take = ov > v || (ov == v && oi < i);
+        v = take ? ov : v; i = take ? oi : i; aux = take ? oa : aux;
+    }
+}
+
+// (row, column <= row) of entry e of a lower triangle stored row by row
+__device__ __forceinline__ void tri_decode(int e, int& i, int& j)
+{
+    i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    j = e - i * (i + 1) / 2;
+}
+
+// Cholesky of a symmetric positive semi-definite matrix by ALL threads of the signal (the wave form below is the faster one for
+// the handful of atoms of a usual group; this one for a factor that lives in global memory): right-looking, per column the scaled
+// column, a barrier, the trailing triangle spread over the threads, a barrier.  dead(j, pivot) marks a column the earlier ones
+// already span: it is skipped -- its row keeps the coefficients that express it through them, its own column is zero -- which IS
+// the factor G = L L^T of the semi-definite matrix with the zero columns left in place.  Returns the number of dead columns.
+template <typename GET, typename SET, typename DEAD, typename SY>
+__device__ __forceinline__ int wg_cholesky(int n, GET get, SET set, DEAD dead_test, SY& sy)
+{
+    const int tid = ltid();
+    int nd = 0;
+    for (int j = 0; j < n; ++j) {
+        const double piv = get(j, j);
+        const bool dead = dead_test(j, piv);                       // uniform
+        const double ljj = dead ? 0.0 : sqrt(piv);
+        for (int r = j + 1 + tid; r < n; r += kThreads) set(r, j, dead ? 0.0 : get(r, j) / ljj);
+        sy.full();
+        if (tid == 0) set(j, j, ljj);
+        if (!dead) {
+            const int M = n - j - 1, tot = M * (M + 1) / 2;
+            for (int e = tid; e < tot; e += kThreads) {
+                int ri, ci;
+                tri_decode(e, ri, ci);
+                const int r = j + 1 + ri, q = j + 1 + ci;
+                set(r, q, get(r, q) - get(r, j) * get(q, j));
+            }
+        }
+        sy.full();
+        nd += dead ? 1 : 0;
+    }
+    return nd;
+}
+// x = (L L^T)^-1 v in place, L a lower factor with no (or explicitly zero) dead diagonal entries; column-oriented, one barrier per
+// column: every thread reads v[i] and L[i][i], the rows behind (in front of) i take their update, thread 0 stores the result
+template <typename GET, typename VGET, typename VSET, typename SY>
+__device__ __forceinline__ void wg_solve(int n, GET get, VGET vget, VSET vset, SY& sy)
+{
+    const int tid = ltid();
+    for (int i = 0; i < n; ++i) {                                  // L y = v
+        const double d = get(i, i), yi = d > 0.0 ? vget(i) / d : 0.0;
+        for (int r = i + 1 + tid; r < n; r += kThreads) vset(r, vget(r) - get(r, i) * yi);
+        sy.full();
+        if (tid == 0) vset(i, yi);
+    }
+    sy.full();
+    for (int i = n - 1; i >= 0; --i) {                             // L^T x = y
+        const double d = get(i, i), xi = d > 0.0 ? vget(i) / d : 0.0;
+        for (int q = tid; q < i; q += kThreads) vset(q, vget(q) - get(i, q) * xi);
+        sy.full();
+        if (tid == 0) vset(i, xi);
+    }
+    sy.full();
+}
+
 // One selected atom (p, k, c): modeling.py:1314-1383.  All threads of the signal's workgroup; the caller leaves the atom
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
@@ -337,6 +444,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
     typename Pol::Lds& L = Pol::group(P, A, plds);
     constexpr int kCap = Pol::kMaxGroup;
+    const GroupGlobal GG = group_global(G.lgram, P.lg_cap);
     HSCMP_STAMP_BEGIN();
     // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
     if (tid == 0) {
@@ -361,19 +469,54 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     sy.full();
     HSCMP_STAMP(0);                                              // neighbourhood scan
     const int m = L.cnt;
-    if (m > kCap - 1) {                                          // uniform
+    if (m > P.lg_cap - 1) {                                      // uniform: beyond the signal's scratch too (hscmp_params / HSCMP_LOCOMP_GROUP_CAP)
         if (tid == 0) { sh.converged = 1; sh.stop = STOP_GROUP; sh.skip = 1; }
         sy.full();
         return;
     }
-    // group order: the new atom, then the neighbours by (position, atom) -- the order of the reference's sparse slice
-    if (tid < m) {
-        const long long key = ((long long)L.ut[tid] << 32) | (unsigned)L.uk[tid];
-        int rank = 0;
-        for (int q = 0; q < m; ++q) rank += ((((long long)L.ut[q] << 32) | (unsigned)L.uk[q]) < key) ? 1 : 0;
-        L.t[1 + rank] = L.ut[tid]; L.k[1 + rank] = L.uk[tid]; L.si[1 + rank] = L.usi[tid];
+    // more neighbours than the LDS lists hold: the lists of this group live in the signal's global scratch
+    const bool bigL = m > kCap - 1;                              // uniform
+    if (bigL) {
+        sy.full();                                               // (everybody has read the count)
+        if (tid == 0) L.cnt = 0;
+        sy.full();
+        for (int i = tid; i < ns; i += kThreads) {
+            const int ti = G.slot_t[i], ki = G.slot_k[i];
+            if (ti < nstart || ti > nend || ki == k || (ti - nstart) == p) continue;
+            if (!(G.slot_a[i] != 0.0)) continue;
+            const int o = atomicAdd(&L.cnt, 1);
+            gst(GG.ut + o, ti); gst(GG.uk + o, ki); gst(GG.usi + o, i);
+        }
+        sy.full();
     }
-    if (tid == 0) { L.n = 1 + m; L.a[0] = c; }
+    auto T_ = [&](int i) -> int { return bigL ? gld(GG.t + i) : L.t[i]; };
+    auto K_ = [&](int i) -> int { return bigL ? gld(GG.k + i) : L.k[i]; };
+    auto SI_ = [&](int i) -> int { return bigL ? gld(GG.si + i) : L.si[i]; };
+    auto A_ = [&](int i) -> R { return bigL ? (R)gld(GG.a + i) : L.a[i]; };
+    auto setA = [&](int i, R v) { if (bigL) gst(GG.a + i, (double)v); else L.a[i] = v; };
+    auto B_ = [&](int i) -> double { return bigL ? gld(GG.b + i) : L.b[i]; };
+    auto setB = [&](int i, double v) { if (bigL) gst(GG.b + i, v); else L.b[i] = v; };
+    auto Dg_ = [&](int i) -> double { return bigL ? gld(GG.diag + i) : L.diag[i]; };
+    auto setDg = [&](int i, double v) { if (bigL) gst(GG.diag + i, v); else L.diag[i] = v; };
+    auto UT_ = [&](int i) -> int { return bigL ? gld(GG.ut + i) : L.ut[i]; };
+    auto setUT = [&](int i, int v) { if (bigL) gst(GG.ut + i, v); else L.ut[i] = v; };
+    // group order: the new atom, then the neighbours by (position, atom) -- the order of the reference's sparse slice
+    for (int i = tid; i < m; i += kThreads) {
+        const int ui = UT_(i), uki = bigL ? gld(GG.uk + i) : L.uk[i], usi = bigL ? gld(GG.usi + i) : L.usi[i];
+        const long long key = ((long long)ui << 32) | (unsigned)uki;
+        int rank = 0;
+        for (int q = 0; q < m; ++q) {
+            const int uq = UT_(q), ukq = bigL ? gld(GG.uk + q) : L.uk[q];
+            rank += ((((long long)uq << 32) | (unsigned)ukq) < key) ? 1 : 0;
+        }
+        if (bigL) { gst(GG.t + 1 + rank, ui); gst(GG.k + 1 + rank, uki); gst(GG.si + 1 + rank, usi); }
+        else { L.t[1 + rank] = ui; L.k[1 + rank] = uki; L.si[1 + rank] = usi; }
+    }
+    if (tid == 0) {
+        L.n = 1 + m;
+        if (bigL) { gst(GG.t, p); gst(GG.k, k); gst(GG.si, L.si[0]); gst(GG.a, (double)c); }
+        else L.a[0] = c;
+    }
     sy.full();
     const int n = 1 + m;
     HSCMP_STAMP(1);                                              // group order
@@ -383,9 +526,9 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
 
     // the Gram matrix: in LDS, or -- a group larger than the policy keeps there -- in the signal's global scratch (through L2)
     const bool big = n > Pol::Lds::kLdsGroup;                // uniform
-    double* gglob = G.lgram;
-    auto gl = [&](int idx) -> double { return big ? __hip_atomic_load(gglob + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : L.g[idx]; };
-    auto gs = [&](int idx, double v) { if (big) __hip_atomic_store(gglob + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else L.g[idx] = v; };
+    double* gglob = GG.gram;
+    auto gl = [&](int idx) -> double { return big ? gld(gglob + idx) : L.g[idx]; };
+    auto gs = [&](int idx, double v) { if (big) gst(gglob + idx, v); else L.g[idx] = v; };
     if (n > 1) {
         // ---- :1322-1329 least squares of the local residual on the group's (clipped) atoms: G x = b, float64
         // items: n right-hand sides, then the n (n + 1) / 2 Gram entries; one wave per item, lanes over the elements
@@ -396,17 +539,16 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             for (int it = tid; it < nitems; it += kThreads) {
                 double acc = 0.0;
                 if (it < n) {
-                    const int ti = L.t[it] - P.off, ki = L.k[it];
+                    const int ti = T_(it) - P.off, ki = K_(it);
                     for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
                         const int wf = nzwf[e], row = ti + (wf >> 16);
                         if (row >= 0 && row < T) acc += (double)nzv[e] * (double)G.r[(int64_t)row * F + (wf & 0xffff)];
                     }
-                    L.b[it] = acc;
+                    setB(it, acc);
                 } else {
-                    int q = it - n, i = 0;
-                    while ((i + 1) * (i + 2) / 2 <= q) ++i;
-                    const int j = q - i * (i + 1) / 2;
-                    const int ti = L.t[i] - P.off, tj = L.t[j] - P.off, ki = L.k[i], kj = L.k[j];
+                    int i, j;
+                    tri_decode(it - n, i, j);
+                    const int ti = T_(i) - P.off, tj = T_(j) - P.off, ki = K_(i), kj = K_(j);
                     const int ej0 = nzp[kj], ej1 = nzp[kj + 1];
                     for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
                         const int wf = nzwf[e], row = ti + (wf >> 16);
@@ -417,7 +559,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                             if (nzwf[e2] == want) acc += (double)nzv[e] * (double)nzv[e2];
                     }
                     gs(L.at(i, j), acc);
-                    if (i == j) L.diag[i] = acc;
+                    if (i == j) setDg(i, acc);
                 }
             }
         } else
@@ -425,70 +567,175 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             double acc = 0.0;
             if (it < n) {
                 int s, e, es;
-                const int len = centered_span(T, W, L.t[it], s, e, es);
-                const R* dk = S.D + ((int64_t)L.k[it] * W + es) * F;
+                const int len = centered_span(T, W, T_(it), s, e, es);
+                const R* dk = S.D + ((int64_t)K_(it) * W + es) * F;
                 const R* rv = G.r + (int64_t)s * F;
                 for (int i = lane; i < len * F; i += 64) acc += (double)dk[i] * (double)rv[i];
                 acc = wave_sum_f64(acc);
-                if (lane == 0) L.b[it] = acc;
+                if (lane == 0) setB(it, acc);
             } else {
                 // (row i, column j <= i) from the linear index of the lower triangle
-                int q = it - n, i = 0;
-                while ((i + 1) * (i + 2) / 2 <= q) ++i;
-                const int j = q - i * (i + 1) / 2;
+                int i, j;
+                tri_decode(it - n, i, j);
                 int si_, ei_, esi, sj_, ej_, esj;
-                centered_span(T, W, L.t[i], si_, ei_, esi);
-                centered_span(T, W, L.t[j], sj_, ej_, esj);
+                centered_span(T, W, T_(i), si_, ei_, esi);
+                centered_span(T, W, T_(j), sj_, ej_, esj);
                 const int lo = max(si_, sj_), hi = min(ei_, ej_);
                 if (hi > lo) {
-                    const R* di = S.D + ((int64_t)L.k[i] * W + (lo - si_ + esi)) * F;
-                    const R* dj = S.D + ((int64_t)L.k[j] * W + (lo - sj_ + esj)) * F;
+                    const R* di = S.D + ((int64_t)K_(i) * W + (lo - si_ + esi)) * F;
+                    const R* dj = S.D + ((int64_t)K_(j) * W + (lo - sj_ + esj)) * F;
                     for (int x = lane; x < (hi - lo) * F; x += 64) acc += (double)di[x] * (double)dj[x];
                     acc = wave_sum_f64(acc);
                 }
-                if (lane == 0) { gs(L.at(i, j), acc); if (i == j) L.diag[i] = acc; }
+                if (lane == 0) { gs(L.at(i, j), acc); if (i == j) setDg(i, acc); }
             }
         }
         sy.full();
         HSCMP_STAMP(2);                                          // right-hand sides + Gram entries
-        // Cholesky of the Gram matrix by one wave (lane = rows lane, lane + 64), right-looking; a pivot that vanishes against its own
-        // diagonal marks an atom that the others already span: it keeps coefficient 0 (the pseudo-inverse would spread it)
-        if (wv == 0) {
-            for (int j = 0; j < n; ++j) {
-                const double piv = gl(L.at(j, j));
-                const bool dead = !(piv > kLocompDead * L.diag[j]);            // uniform
-                const double ljj = dead ? 0.0 : sqrt(piv);
-                if (lane == 0) gs(L.at(j, j), ljj);
-                for (int r = lane; r < n; r += 64)
-                    if (r > j) {
-                        const double lij = dead ? 0.0 : gl(L.at(r, j)) / ljj;
-                        gs(L.at(r, j), lij);
+        // Cholesky WITH DIAGONAL PIVOTING of the Gram matrix: at every step the largest remaining diagonal entry of the Schur
+        // complement is the pivot; the factorisation ends when that entry no longer exceeds kLocompRankTol x the largest original
+        // one -- what is left then is round-off RELATIVE TO THE MATRIX (Higham, "Analysis of the Cholesky decomposition of a
+        // semi-definite matrix"), whatever the conditioning of the atoms already taken: without pivoting the Schur complement of a
+        // dependent atom carries eps x cond of its predecessors, 4e-12 of its own norm in one of the reference's goldens.  Pivoting
+        // is virtual: the pivot order perm[] / pos[] is recorded, L[i][step s] stays at the packed entry (i, perm[s]) of the
+        // symmetric matrix, which the Schur complement no longer needs.  All atoms taken (every group of independent atoms):
+        // x = G^-1 b by two substitutions in pivot order.  Otherwise the group is rank deficient and the reference's np.linalg.pinv
+        // (:1326), which cuts the vanishing singular values, returns the MINIMUM-NORM least-squares solution; so does the
+        // completion below.
+        auto sym = [&](int i, int j) -> int { return i >= j ? L.at(i, j) : L.at(j, i); };
+        auto PERM_ = UT_;                                          // pivot of step s            (the free list `ut`)
+        auto POS_ = [&](int i) -> int { return bigL ? gld(GG.usi + i) : L.usi[i]; };      // step at which atom i was taken, -1: not (yet)
+        auto setPOS = [&](int i, int v) { if (bigL) gst(GG.usi + i, v); else L.usi[i] = v; };
+        int rank;
+        if (!big) {
+            // one wave, lane = atom (n <= 64: the Gram matrix is in LDS)
+            if (wv == 0) {
+                int rk = 0;
+                unsigned long long done = 0ull;
+                double dmax0 = 0.0;
+                if (lane < n) L.usi[lane] = -1;
+                for (int s_ = 0; s_ < n; ++s_) {
+                    double v = (lane < n && !((done >> lane) & 1ull)) ? L.g[L.at(lane, lane)] : -1.0;
+                    int idx = lane;
+                    wave_argmax_f64(v, idx);
+                    if (s_ == 0) dmax0 = v;
+                    if (!(v > kLocompRankTol * dmax0)) break;                     // uniform
+                    const int pp = idx;
+                    const double ljj = sqrt(v);
+                    if (lane == 0) { L.g[L.at(pp, pp)] = ljj; L.ut[s_] = pp; L.usi[pp] = s_; }
+                    done |= 1ull << pp;
+                    const bool mine = lane < n && !((done >> lane) & 1ull);
+                    double lrp = 0.0;
+                    if (mine) { lrp = L.g[sym(lane, pp)] / ljj; L.g[sym(lane, pp)] = lrp; }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (mine)
+                        for (int q = 0; q <= lane; ++q)
+                            if (!((done >> q) & 1ull)) L.g[L.at(lane, q)] -= lrp * L.g[sym(q, pp)];
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    ++rk;
+                }
+                if (lane == 0) {
+                    L.cnt = rk;
+                    if (rk == n) {
+                        // forward (L y = b), then backward (L^T z = y), in pivot order; x[perm[s]] = z[s]
+                        for (int i = 0; i < n; ++i) {
+                            const int pi = L.ut[i];
+                            double v = L.b[pi];
+                            for (int q = 0; q < i; ++q) v -= L.g[sym(pi, L.ut[q])] * L.diag[q];
+                            L.diag[i] = v / L.g[L.at(pi, pi)];
+                        }
+                        for (int i = n - 1; i >= 0; --i) {
+                            const int pi = L.ut[i];
+                            double v = L.diag[i];
+                            for (int q = i + 1; q < n; ++q) v -= L.g[sym(L.ut[q], pi)] * L.diag[q];
+                            L.diag[i] = v / L.g[L.at(pi, pi)];
+                        }
+                        for (int i = 0; i < n; ++i) { const int pi = L.ut[i]; L.b[pi] = L.diag[i]; L.a[pi] = (R)L.diag[i]; }
                     }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                for (int r = lane; r < n; r += 64)
-                    if (r > j) {
-                        const double lij = gl(L.at(r, j));
-                        for (int q = j + 1; q <= r; ++q) gs(L.at(r, q), gl(L.at(r, q)) - lij * gl(L.at(q, j)));
-                    }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
             }
-            if (lane == 0) {
-                // forward (L y = b), then backward (L^T x = y); a dead atom keeps 0
-                for (int i = 0; i < n; ++i) {
-                    double v = L.b[i];
-                    for (int q = 0; q < i; ++q) v -= gl(L.at(i, q)) * L.b[q];
+            sy.full();
+            rank = L.cnt;
+        } else {
+            // all threads, the matrix in global memory; the atoms not yet taken as a list (`uk`), so that the trailing update
+            // walks the pairs of what is left
+            auto ACT_ = [&](int i) -> int { return bigL ? gld(GG.uk + i) : L.uk[i]; };
+            auto setACT = [&](int i, int v) { if (bigL) gst(GG.uk + i, v); else L.uk[i] = v; };
+            for (int i = tid; i < n; i += kThreads) { setPOS(i, -1); setACT(i, i); }
+            sy.full();
+            int rk = 0, na = n;
+            double dmax0 = 0.0;
+            for (int s_ = 0; s_ < n; ++s_) {
+                double v = -1.0;
+                int idx = 0x7fffffff, slot = -1;
+                for (int a_ = lane; a_ < na; a_ += 64) {
+                    const int i = ACT_(a_);
                     const double d = gl(L.at(i, i));
-                    L.b[i] = d > 0.0 ? v / d : 0.0;
+                    if (d > v || (d == v && i < idx)) { v = d; idx = i; slot = a_; }
                 }
-                for (int i = n - 1; i >= 0; --i) {
-                    double v = L.b[i];
-                    for (int q = i + 1; q < n; ++q) v -= gl(L.at(q, i)) * L.b[q];
-                    const double d = gl(L.at(i, i));
-                    L.b[i] = d > 0.0 ? v / d : 0.0;
+                wave_argmax_f64(v, idx, slot);                     // (every wave finds the same pivot)
+                if (s_ == 0) dmax0 = v;
+                if (!(v > kLocompRankTol * dmax0)) break;           // uniform
+                const int pp = idx;
+                const double ljj = sqrt(v);
+                const int last = ACT_(na - 1);
+                sy.full();                                         // (everybody has read the diagonal and the list)
+                if (tid == 0) { gs(L.at(pp, pp), ljj); setUT(s_, pp); setPOS(pp, s_); setACT(slot, last); }
+                --na;
+                sy.full();
+                for (int a_ = tid; a_ < na; a_ += kThreads) { const int r = ACT_(a_); gs(sym(r, pp), gl(sym(r, pp)) / ljj); }
+                sy.full();
+                for (int e = tid; e < na * (na + 1) / 2; e += kThreads) {
+                    int ai, bi;
+                    tri_decode(e, ai, bi);
+                    const int r = ACT_(ai), q = ACT_(bi);
+                    gs(sym(r, q), gl(sym(r, q)) - gl(sym(r, pp)) * gl(sym(q, pp)));
                 }
-                for (int i = 0; i < n; ++i) L.a[i] = (R)L.b[i];
+                sy.full();
+                ++rk;
+            }
+            rank = rk;
+            if (rank == n) {
+                for (int i = tid; i < n; i += kThreads) setDg(i, B_(PERM_(i)));
+                sy.full();
+                wg_solve(n, [&](int i, int j) { return gl(sym(PERM_(i), PERM_(j))); }, Dg_, setDg, sy);
+                for (int i = tid; i < n; i += kThreads) { const int pi = PERM_(i); const double x = Dg_(i); setB(pi, x); setA(pi, (R)x); }
+            }
+        }
+        if (rank < n) {
+            // ---- minimum-norm solution x = G^+ b of the rank-deficient group.  G = L L^T with L [n x rank] of full column rank
+            // (row i: the atom, column s: the pivot step; an atom taken at step s' has zeros behind column s'), so
+            // G^+ = L (L^T L)^-2 L^T:  u = L^T b,  S = L^T L,  v = S^-1 u,  w = S^-1 v,  x = L w.
+            // Rare (a composite atom together with all of its singletons, a group that fills its whole signal): all threads,
+            // S in the signal's global scratch.
+            sy.full();
+            auto Lf = [&](int i, int s_) -> double { const int ps = POS_(i); return (ps < 0 || ps >= s_) ? gl(sym(i, PERM_(s_))) : 0.0; };
+            auto sget = [&](int i, int j) -> double { return gld(GG.s + (int64_t)i * (i + 1) / 2 + j); };
+            auto sset = [&](int i, int j, double v) { gst(GG.s + (int64_t)i * (i + 1) / 2 + j, v); };
+            for (int it = tid; it < rank + rank * (rank + 1) / 2; it += kThreads) {
+                double acc = 0.0;
+                if (it < rank) {
+                    for (int i = 0; i < n; ++i) acc += Lf(i, it) * B_(i);
+                    gst(GG.w + it, acc);                                               // u
+                } else {
+                    int pi, qi;
+                    tri_decode(it - rank, pi, qi);
+                    for (int i = 0; i < n; ++i) acc += Lf(i, pi) * Lf(i, qi);
+                    sset(pi, qi, acc);
+                }
+            }
+            sy.full();
+            wg_cholesky(rank, sget, sset, [&](int, double piv) { return !(piv > 0.0); }, sy);
+            auto wget = [&](int i) -> double { return gld(GG.w + i); };
+            auto wset = [&](int i, double v) { gst(GG.w + i, v); };
+            wg_solve(rank, sget, wget, wset, sy);
+            wg_solve(rank, sget, wget, wset, sy);
+            for (int i = tid; i < n; i += kThreads) {
+                double x = 0.0;
+                for (int q = 0; q < rank; ++q) x += Lf(i, q) * wget(q);
+                setB(i, x); setA(i, (R)x);
             }
         }
         sy.full();
@@ -497,7 +744,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
 
     // ---- :1336-1341 / :1345-1350 coefficients += fitted; residual -= fitted * atom, with the local energies (:996-1016)
     auto book = [&](int gi, int tp, int kk, R cf) {                      // (one thread)
-        int si = L.si[gi];
+        int si = SI_(gi);
         double before = 0.0;
         if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }
         else before = G.slot_a[si];
@@ -517,8 +764,8 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     if (wave_apply) {
         if (wv == 0)
             for (int gi = 0; gi < n; ++gi) {
-                const int tp = L.t[gi], kk = L.k[gi];
-                const R cf = L.a[gi];
+                const int tp = T_(gi), kk = K_(gi);
+                const R cf = A_(gi);
                 if (lane == 0) book(gi, tp, kk, cf);
                 int s, e, es;
                 const int cnt = centered_span(T, W, tp, s, e, es) * F;
@@ -563,8 +810,8 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         sy.full();
     } else
     for (int gi = 0; gi < n; ++gi) {
-        const int tp = L.t[gi], kk = L.k[gi];
-        const R cf = L.a[gi];
+        const int tp = T_(gi), kk = K_(gi);
+        const R cf = A_(gi);
         if (tid == 0) book(gi, tp, kk, cf);
         int s, e, es;
         const int len = centered_span(T, W, tp, s, e, es);
@@ -608,7 +855,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     if (P.has_scale)
         for (int gi = 0; gi < n; ++gi) {
             int s, e, es;
-            centered_span(T, W, L.t[gi], s, e, es);
+            centered_span(T, W, T_(gi), s, e, es);
             const int sg0 = s >> P.seg_shift, sg1 = (e - 1) >> P.seg_shift;
             for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) rscan_segment(P, G, sh, sg, lane);
         }
@@ -620,7 +867,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     int pmin = p, pmax = p;
     if (joint)
         for (int gi = 0; gi < n; ++gi) {                               // uniform
-            const int tp = L.t[gi];
+            const int tp = T_(gi);
             joint = joint && tp - P.off - (W - 1) >= 0 && tp + W / 2 + (W - 1) <= T - 1;      // interior: no padding in its rows (:1028-1046)
             pmin = min(pmin, tp); pmax = max(pmax, tp);
         }
@@ -629,12 +876,12 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         sy.full();
     } else
     for (int gi = 0; gi < n; ++gi) {
-        Pol::lrun(P, S, G, sh, A, plds, L.t[gi], L.k[gi], sy);
+        Pol::lrun(P, S, G, sh, A, plds, T_(gi), K_(gi), sy);
         sy.full();
     }
     HSCMP_STAMP(5);                                                      // re-correlation
     for (int gi = 0; gi < n; ++gi) {
-        const int tp = L.t[gi];
+        const int tp = T_(gi);
         const int lo = max(0, tp - (W - 1)), hi = min(T - 1, tp + (W - 1));
         const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
         if (P.blocked) {

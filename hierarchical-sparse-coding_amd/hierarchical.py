@@ -343,7 +343,8 @@ class _LevelPipeline(object):
                 out = [_slots_to_csc(st[b], sk[b], sa[b], int(stats[b, _native.STAT_SLOTS]), (self.T, K), 1e-16) for b in range(count)]
         tm = dict(variant=eng.last_variant(), kernel_ms=kernel_ms,
                   selections=int(stats[:, _native.STAT_ITERATIONS].sum()), duplicates=int(stats[:, _native.STAT_DUPLICATES].sum()),
-                  rounds=int(stats[:, _native.STAT_ROUNDS].sum()))
+                  rounds=int(stats[:, _native.STAT_ROUNDS].sum()),
+                  stops={_native.STOP_NAMES.get(int(c), str(c)): int(n_) for c, n_ in zip(*np.unique(stats[:, _native.STAT_STOP], return_counts=True))})
         return out, tm, stats
 
     # ---- host copies of the inputs
@@ -412,6 +413,8 @@ class _LevelPipeline(object):
             if coefs is not None:
                 self.per_level[l][first:first + count] = coefs
             acc = self.timings[l]
+            for name_, n_ in tm['stops'].items():
+                acc.setdefault('stops', {})[name_] = acc.setdefault('stops', {}).get(name_, 0) + n_
             acc['variant'] = tm['variant']; acc['selections'] += tm['selections']; acc['duplicates'] += tm['duplicates']; acc['rounds'] += tm['rounds']; acc['chunks'] += 1
             acc['kernel_ms'] = [a + b for a, b in zip(acc['kernel_ms'], tm['kernel_ms'])]
         return last_stats

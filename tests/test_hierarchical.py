@@ -259,8 +259,7 @@ def test_hierarchical_batch_with_locomp_runs_the_device_loop_on_every_level():
     """The batch entry point with the reference's default method ('locomp'): the chained pipeline of method='cmp' with every
     level's engine on the LoCOMP loop (csrc/hscmp_locomp.h).  Deterministic, the same from the device and the host epilogue,
     the residual is the signal minus the reconstruction of the returned code, and level 0 equals the stand-alone batch LoCOMP.
-    (Against the per-signal entry -- the reference's own pseudo-inverse on the host -- a cascade of levels only agrees loosely:
-    the two solvers differ in the last bits, and an ill-conditioned group downstream amplifies that; see DESIGN.md.)"""
+    (Against the per-signal entry -- the reference's own pseudo-inverse on the host -- see the comment at the end.)"""
     from hsc_amd.modeling import HierarchicalConvolutionalMatchingPursuit, LoCOMP
     z = _golden()
     mld = _mld().withSingletonBases()
@@ -285,11 +284,25 @@ def test_hierarchical_batch_with_locomp_runs_the_device_loop_on_every_level():
     alone = LoCOMP().computeCoefficientsBatch(xs, D0, toleranceSnr=10.0, nbBlocks=4, weights=np.ones((D0.shape[0],), dtype=D0.dtype))
     for b in range(xs.shape[0]):
         assert (scipy.sparse.csc_matrix(first[b][0]) != alone.coefficients[b]).nnz == 0
-    # loose agreement with the per-signal entry: the same number of level-0 atoms within a quarter, on every signal
+    # Against the host loop (np.linalg.pinv in the dictionary's dtype, as the reference): level by level ON THE SAME INPUT -- the
+    # host loop's own output of the level below -- so that no cascade is involved.  What remains between the two is (a) entries
+    # that are exactly 0.0 in the float64 re-fit and ~1e-8 in the reference's float32 pseudo-inverse (they count in nnz, not in
+    # value), (b) stops decided by round-off ('stalled': |dE| < eps of the float32 dictionary, modeling.py:1379), after which one of
+    # the two runs a few atoms longer.  Values agree wherever both have an entry of size; the reference goldens of the batch path
+    # (tests/test_locomp_hier.py) are the tight comparison.
+    snr = kw['toleranceSnr']
     for b in range(0, xs.shape[0], 3):
-        c1, _ = hcmp.computeCoefficients(xs[b], mld, returnDistributed=False, **kw)
-        cb, _, _ = hcmp.computeCoefficientsBatch(xs[b:b + 1], mld, returnDistributed=False, **kw)
-        assert abs(cb[0][2].nnz - c1[2].nnz) <= max(4, c1[2].nnz // 4)
+        inp = xs[b]
+        for level in range(3):
+            D = mld.getRawDictionary(level)
+            w = np.ones(D.shape[0], dtype=D.dtype); w[:D.shape[0] - mld.countsNoSingletons[level]] = 0.5
+            res = LoCOMP().computeCoefficientsBatch(np.asarray(inp)[None], D, toleranceSnr=snr[level], nbBlocks=4, weights=w)
+            ch, _ = LoCOMP(refit='host').computeCoefficients(np.asarray(inp), D, toleranceSnr=snr[level], nbBlocks=4, weights=w)
+            a, h = res.coefficients[0].tocsc(), ch.tocsc()
+            big_a, big_h = int((abs(a.data) > 1e-6).sum()), int((abs(h.data) > 1e-6).sum())
+            assert abs(big_a - big_h) <= max(3, big_h // 8), (b, level, big_a, big_h)
+            assert float(abs(a - h).max()) <= 0.05 * float(abs(h).max()), (b, level)
+            inp = ch.toarray()
     hcmp.close()
 
 

@@ -13,6 +13,9 @@ Files written:
   tests/golden/cmp_config.npz   -- BASELINE config 1 (T=4096) and 8 full-size config-2 signals
                                    (T=65536, K=256, W=64, L0=256): outputs + input digests
   tests/golden/locomp_small.npz -- LoCOMP (modeling.py:1191-1425) on small seeded problems
+  tests/golden/locomp_hier.npz  -- the hierarchical encoder with its default method='locomp' (config-4 dimensions, a generated
+                                   3-level dictionary in float32 and float64) and single-level LoCOMP on rank-deficient groups, each
+                                   with the conditioning the reference's pseudo-inverse saw
   tests/golden/synth_small.npz  -- dataset synthesis (hsc/dataset.py:412-796) under fixed numpy seeds: generated
                                    multilevel dictionaries (raw, representations, decompositions), Poisson
                                    events with / without rate scaling, rendered signals
@@ -501,6 +504,187 @@ def gen_locomp():
     print('locomp_small.npz: %d cases' % len(names))
 
 
+
+class _PinvProbe(object):
+    """np.linalg.pinv of the reference's LoCOMP (modeling.py:1326), observed: per call the group size, the singular values the
+    pseudo-inverse keeps (rcond = 1e-15 of the largest, in the matrix's dtype) and how many it cuts."""
+
+    def __init__(self, ref):
+        self.ref, self.rec = ref, []
+        self.orig = np.linalg.pinv
+
+    def __enter__(self):
+        def pinv(a, *args, **kw):
+            s = np.linalg.svd(a, compute_uv=False)            # (the dtype the reference's own call works in)
+            keep = s > 1e-15 * s[0]
+            self.rec.append((a.shape[0], a.shape[1], int(np.sum(~keep)) + max(0, a.shape[0] - len(s)), float(s[keep][-1] / s[0])))
+            return self.orig(a, *args, **kw)
+        self.ref.modeling.np.linalg.pinv = pinv
+        del self.rec[:]
+        return self
+
+    def __exit__(self, *exc):
+        self.ref.modeling.np.linalg.pinv = self.orig
+
+    def summary(self, out, prefix):
+        r = np.array(self.rec, dtype=np.float64) if self.rec else np.zeros((0, 4))
+        out[prefix + '__groups'] = np.int64(len(r))
+        out[prefix + '__group_max'] = np.int64(r[:, 0].max() if len(r) else 0)
+        out[prefix + '__groups_cut'] = np.int64(int((r[:, 2] > 0).sum()) if len(r) else 0)       # groups with a cut singular value
+        out[prefix + '__min_rel_sigma_kept'] = np.float64(r[:, 3].min() if len(r) else 1.0)         # 1 / condition of the worst group
+        return r
+
+
+def rank_deficient_case(seed, dt, F=6, W=7, ncomp=5, T=200, nev=20):
+    """A multi-feature dictionary of singletons (one cell) and composites (two cells), and a signal in which every planted
+    composite comes with the singletons of its two cells: the greedy selection puts all three into one group, whose local
+    dictionary is exactly rank deficient (hierarchical levels >= 1 look like this: hsc/dataset.py:826-860)."""
+    rs = np.random.RandomState(seed)
+    K = F + ncomp
+    D = np.zeros((K, W, F))
+    c = (W - 1) // 2
+    for f in range(F):
+        D[f, c, f] = 1.0
+    for k in range(F, K):
+        for _ in range(2):
+            D[k, rs.randint(0, W), rs.randint(0, F)] = rs.uniform(0.5, 1.5) * rs.choice([-1.0, 1.0])
+        D[k] /= np.sqrt(np.sum(D[k] ** 2))
+    x = np.zeros((T, F))
+    for _ in range(nev):
+        k = rs.randint(0, K); t = rs.randint(0, T - W)
+        x[t:t + W] += rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0]) * D[k]
+        if k >= F:
+            for (w_, f_) in zip(*np.nonzero(D[k])):
+                x[t + w_, f_] += rs.uniform(0.5, 2.0) * rs.choice([-1.0, 1.0])
+    x += 0.01 * rs.standard_normal((T, F)) * (rs.rand(T, F) < 0.1)
+    w = np.ones(K); w[:F] = 0.9
+    return x.astype(dt), D.astype(dt), dict(toleranceSnr=40.0, nbBlocks=2, weights=w.astype(dt), nbNonzeroCoefs=150)
+
+
+def gen_locomp_hier():
+    """The reference's DEFAULT hierarchical method (modeling.py:1429 method='locomp') and its re-fit on rank-deficient groups:
+    tests/golden/locomp_hier.npz.
+      c4w16 / c4w17   2-level encode at the BASELINE config-4 dictionary dimensions, 8192 samples (inputs by seed: hsc_amd.synth)
+      gen3 / gen3_f64 3-level encode on a generated dictionary (Perlin, scales [16, 32, 64]; inputs by numpy seed), float32 as
+                      generated and float64 (the reference's default dtype)
+      rd_*            single-level LoCOMP on groups that are exactly rank deficient (a composite atom beside its singletons):
+                      np.linalg.pinv cuts the vanishing singular value and returns the minimum-norm re-fit
+      soak_*          the draws of tests/test_gpu_fuzz.py::_draw whose groups fill their whole (tiny) signal
+    Every case carries what the reference's pseudo-inverse saw: number of groups, largest group, groups with a cut singular value,
+    the smallest kept singular value relative to the largest (= 1 / condition of the worst group)."""
+    import copy
+    import hashlib
+    import logging
+    logging.disable(logging.WARNING)
+    ref = load_reference()
+    out = {}
+    names = []
+
+    def pack_levels(name, coefficients, residual, x):
+        for l, c in enumerate(coefficients):
+            pack_csc('%s__level%d' % (name, l), scipy_sparse(c), out)
+        e = float(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
+        out[name + '__residual_energy'] = np.float64(e)
+        out[name + '__nlevels'] = np.int64(len(coefficients))
+        return 10 * np.log10(np.sum(np.asarray(x, dtype=np.float64) ** 2) / e)
+
+    kw4 = dict(toleranceSnr=[30.0, 40.0], nbBlocks=10, singletonWeight=0.95)
+    for W1 in (16, 17):
+        name = 'c4w%d' % W1
+        D0, decompositions, scales = synth.make_hierarchy_parts(W1=W1, seed=4)
+        mld = ref.dataset.MultilevelDictionary.fromDecompositions(D0, copy.deepcopy(decompositions), np.array(scales))
+        own = synth.make_hierarchy(W1=W1, seed=4)
+        x = synth.make_hierarchy_signal(own, 8192, 0, seed=4)
+        out[name + '__x_digest'] = np.array(synth.digest(x))
+        mlds = mld.withSingletonBases()
+        t0 = time.time()
+        with _PinvProbe(ref) as probe:
+            hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mlds, ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='locomp'))
+            coefficients, residual = hcsc.encode(x, **kw4)
+        probe.summary(out, name)
+        snr = pack_levels(name, coefficients, residual, x)
+        names.append(name)
+        print(name, [c.nnz for c in coefficients], 'SNR %.2f dB' % snr, 'groups', int(out[name + '__groups']), 'max', int(out[name + '__group_max']),
+              'cut', int(out[name + '__groups_cut']), 'min rel sigma %.3g' % float(out[name + '__min_rel_sigma_kept']), '%.1f s' % (time.time() - t0))
+
+    kw3 = dict(toleranceSnr=[20.0, 30.0, 30.0], nbBlocks=10, singletonWeight=0.9)
+    for name, dt in (('gen3', np.float32), ('gen3_f64', np.float64)):
+        np.random.seed(77)
+        mld = ref.dataset.MultilevelDictionaryGenerator().generate(scales=[16, 32, 64], counts=[16, 24, 32], decompositionSize=3,
+                                                                   multilevelDecomposition=False, maxNbPatternsConsecutiveRejected=50)
+        np.random.seed(78)
+        gen = ref.dataset.SignalGenerator(mld, [0.004, 0.004, 0.004])
+        events = gen.generateEvents(4096)
+        x = gen.generateSignalFromEvents(events, nbSamples=4096)
+        if dt == np.float64:
+            dec64 = [[[d[0], d[1], d[2], np.asarray(d[3], dtype=np.float64)] for d in lev] for lev in copy.deepcopy(mld.decompositions)]
+            mld = ref.dataset.MultilevelDictionary.fromDecompositions(mld.dictionaries[0].astype(np.float64), dec64, mld.scales)
+            assert all(d.dtype == np.float64 for d in mld.dictionaries)
+            x = x.astype(np.float64)
+        out[name + '__x_sha256'] = np.array(hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest())
+        out[name + '__nevents'] = np.int64(len(events))
+        t0 = time.time()
+        with _PinvProbe(ref) as probe:
+            hcsc = ref.modeling.HierarchicalConvolutionalSparseCoder(mld, ref.modeling.HierarchicalConvolutionalMatchingPursuit(method='locomp'))
+            coefficients, residual = hcsc.encode(x, **kw3)
+        probe.summary(out, name)
+        snr = pack_levels(name, coefficients, residual, x)
+        names.append(name)
+        print(name, x.dtype, [c.nnz for c in coefficients], 'SNR %.2f dB' % snr, 'groups', int(out[name + '__groups']), 'max', int(out[name + '__group_max']),
+              'cut', int(out[name + '__groups_cut']), 'min rel sigma %.3g' % float(out[name + '__min_rel_sigma_kept']), '%.1f s' % (time.time() - t0))
+
+    # single-level cases
+    singles = []
+    for dt, tag in ((np.float64, 'f64'), (np.float32, 'f32')):
+        found = 0
+        for seed in range(400):
+            if found >= 5:
+                break
+            x, D, kw = rank_deficient_case(seed, dt)
+            with _PinvProbe(ref) as probe:
+                coef, res = ref.modeling.LoCOMP().computeCoefficients(x, D, **kw)
+            r = np.array(probe.rec, dtype=np.float64) if probe.rec else np.zeros((0, 4))
+            # keep the draws with at least one cut singular value whose KEPT part is well conditioned (the comparison is then at
+            # round-off level, and the cut itself unambiguous: the vanishing value is exactly 0 or below 1e-15 by orders)
+            if len(r) and (r[:, 2] > 0).any() and r[:, 3].min() > 1e-3 and np.all(np.isfinite(res)):
+                singles.append(('rd_%s_s%d' % (tag, seed), x, D, kw, coef, res, list(probe.rec)))
+                found += 1
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_fuzz as fz
+    for i in (29, 53, 117):
+        x, D, kw = fz._draw(i)
+        kw = dict(kw)
+        if kw.get('nbNonzeroCoefs', 0) > 40:
+            kw['nbNonzeroCoefs'] = 40
+        with _PinvProbe(ref) as probe:
+            coef, res = ref.modeling.LoCOMP().computeCoefficients(x, D, **kw)
+        singles.append(('soak_%d' % i, x, D, kw, coef, res, list(probe.rec)))
+    for name, x, D, kw, coef, res, rec in singles:
+        names.append(name)
+        out[name + '__x'] = x; out[name + '__D'] = D
+        for key, val in kw.items():
+            if key == 'weights':
+                out[name + '__weights'] = val
+            elif key == 'nbBlocks':
+                out[name + '__nbBlocks'] = np.array(-1 if val == 'auto' else val)
+            elif val is None:
+                out[name + '__%s_is_none' % key] = np.array(1)
+            else:
+                out[name + '__' + key] = np.array(val)
+        out[name + '__residual'] = res
+        pack_csc(name + '__csc', coef, out)
+        r = np.array(rec, dtype=np.float64) if rec else np.zeros((0, 4))
+        out[name + '__groups'] = np.int64(len(r)); out[name + '__group_max'] = np.int64(r[:, 0].max() if len(r) else 0)
+        out[name + '__groups_cut'] = np.int64(int((r[:, 2] > 0).sum()) if len(r) else 0)
+        out[name + '__min_rel_sigma_kept'] = np.float64(r[:, 3].min() if len(r) else 1.0)
+        print(name, x.shape, D.shape, x.dtype, 'nnz', coef.nnz, 'groups', len(r), 'cut', int(out[name + '__groups_cut']),
+              'min rel sigma kept %.3g' % float(out[name + '__min_rel_sigma_kept']))
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'locomp_hier.npz'), **out)
+    print('wrote locomp_hier.npz', os.path.getsize(os.path.join(OUT, 'locomp_hier.npz')), 'bytes')
+    logging.disable(logging.NOTSET)
+
+
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from golden_util import SYNTH_CASES, LEARN_CASES, learn_signal  # noqa: E402  (case tables shared with the tests)
 
@@ -580,7 +764,7 @@ def scipy_sparse(c):
 if __name__ == '__main__':
     assert load_reference() is not None, 'the reference is not available in this environment'
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'hsc4', 'mldpkl', 'locomp', 'synth', 'learn']
+    which = sys.argv[1:] or ['small', 'functions', 'config', 'hsc', 'hscmed', 'hsc4', 'mldpkl', 'locomp', 'locomphier', 'synth', 'learn']
     if 'small' in which:
         gen_small()
     if 'functions' in which:
@@ -597,6 +781,8 @@ if __name__ == '__main__':
         gen_mld_pickle()
     if 'locomp' in which:
         gen_locomp()
+    if 'locomphier' in which:
+        gen_locomp_hier()
     if 'synth' in which:
         gen_synth()
     if 'learn' in which:
