@@ -48,6 +48,7 @@ template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompL
                                                        // triangle, row i at i (i + 1) / 2
                                           // (a group of more than NG atoms keeps it in global memory: Sig::lgram)
     static constexpr int kLdsGroup = NG;
+    static constexpr int kFastGroup = NG >= 64 ? 32 : 16;   // atoms of a group that is re-fitted in registers (locomp_fast_solve)
     static __device__ __forceinline__ int at(int i, int j) { return i * (i + 1) / 2 + j; }       // (j <= i)
 };
 
@@ -55,6 +56,7 @@ template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompL
 template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;            // (no per-policy residual update: short atoms go through one wave)
+    static constexpr bool kGroupUpdate = false;
     static constexpr bool kUnionRows = false;
     static constexpr bool kOwnInit = false;
     static constexpr int kMaxGroup = kLocompMax;
@@ -79,6 +81,7 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
 // the per-row lists of non-zero cells current, the re-correlation forms the non-zero products only
 template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
+    static constexpr int kMinWavesPerSimd = 2;          // (two workgroups per CU: the register-resident re-fit must not cost the second one)
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = true;
     static constexpr int kMaxGroup = kLocompMax;
@@ -111,6 +114,92 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
         const int first = pmin - (P.W - 1), nrows = (pmax - pmin) + 2 * P.W - 1, step = 2 * P.W - 1;
         for (int r0 = 0; r0 < nrows; r0 += step)
             sparse_rows<R, false>(P, S, G, A, L, bits, first + r0, min(step, nrows - r0), false, 0, 0, false);
+    }
+    // The whole group applied in ONE pass (:1343-1350 removes its atoms one after the other).  The atoms of a level >= 1 dictionary
+    // have a handful of non-zero cells each; the (cell, atom) pairs of the group are laid out in group order, a cell that several
+    // atoms share is walked by the thread of its first pair in that order -- r = ((r + (-a0 d0)) + (-a1 d1)) ..., each product rounded
+    // first: the reference's own sequence of roundings for that cell, and no cell depends on another.  The energy loss of the group
+    // (:998-1014 sums before - after over the atoms' spans) is taken over the cells that change: unchanged cells cancel in it, and
+    // what two atoms do to a shared cell telescopes -- the same number up to the rounding of the two span sums it no longer forms.
+    // The cells are entered in the row lists as SparseRecorr::update_residual does.  Returns false (nothing done) without row lists /
+    // dictionary lists or when the pairs do not fit the policy's LDS lists: the atom-by-atom form then runs.
+    static constexpr bool kGroupUpdate = true;
+    template <typename TF, typename KF, typename AF, typename SY>
+    static __device__ __forceinline__ bool group_update(const DevParams& P, const Sig<R>& G, const Args& A0, char* lds, int n, TF T_, KF K_, AF A_,
+                                                        R& loss, R* red, SY& sy)
+    {
+        if (!A0.rl_cnt) return false;
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        if (!A.nzptr || A.rl_cap != 8) return false;
+        const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
+        const int T = P.T, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
+        if (n + 1 > L.caps.rec) return false;
+        int* off = reinterpret_cast<int*>(L.okey);            // [n + 1] first pair of every atom
+        int* key = L.perm;                                    // [pairs] cell (row * F + feature), -1 - q: clipped
+        R* prod = L.rx;                                       // [pairs] -a * d, rounded (utils.py:120,129)
+        // pairs per atom, prefix sum (one wave, 64 atoms at a time)
+        if (wv == 0) {
+            int base = 0;
+            for (int g0 = 0; g0 < n; g0 += 64) {
+                const int gi = g0 + lane;
+                int c = 0;
+                if (gi < n) { const int kk = K_(gi); c = A.nzptr[kk + 1] - A.nzptr[kk]; }
+                int incl = c;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m); if (lane >= m) incl += o; }
+                if (gi < n) off[gi] = base + incl - c;
+                base += __shfl(incl, 63);
+            }
+            if (lane == 0) { off[n] = base; L.ctl[0] = base; }
+        }
+        sy.lds();
+        const int np = L.ctl[0];
+        if (np > L.caps.rec) return false;                    // uniform
+        for (int q = tid; q < np; q += kThreads) {
+            int lo = 0, hi = n;                               // the atom of pair q: off[gi] <= q < off[gi + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= q) lo = mid; else hi = mid; }
+            const int gi = lo, kk = K_(gi), e = A.nzptr[kk] + (q - off[gi]);
+            const int wf = A.nzwf[e], f = wf & 0xffff, g = T_(gi) - P.off + (wf >> 16);
+            const R nc = -A_(gi);
+            key[q] = (g >= 0 && g < T) ? g * F + f : -1 - q;  // clipped part of the atom (utils.py:110-129)
+            prod[q] = nc * A.nzval[e];
+        }
+        sy.lds();
+        int* cntw = A.rl_cnt + (int64_t)blockIdx.x * T;
+        int* lfw = A.rl_f + (int64_t)blockIdx.x * T * 8;
+        R mine = (R)0;
+        for (int q = tid; q < np; q += kThreads) {
+            const int cell = key[q];
+            if (cell < 0) continue;
+            bool first = true;
+            for (int j = 0; j < q; ++j) first = first && key[j] != cell;
+            if (!first) continue;
+            const int g = cell / F, f = cell - g * F;
+            // (both trips at once: the cell, its row's list)
+            const R vb = G.r[cell];
+            const int n2 = list_count(cntw + g);
+            const int4* row2 = reinterpret_cast<const int4*>(lfw + (int64_t)g * 8);
+            const int4 a2 = row2[0], b2 = row2[1];
+            R v = vb + prod[q];
+            for (int j = q + 1; j < np; ++j) if (key[j] == cell) v = v + prod[j];
+            G.r[cell] = v;
+            const R sb = vb * vb, sa = v * v;
+            const R d = sb - sa;
+            mine = mine + d;
+            const bool listed = n2 > 8 || a2.x == f || a2.y == f || a2.z == f || a2.w == f || b2.x == f || b2.y == f || b2.z == f || b2.w == f;
+            if (!listed) {
+                const int o = atomicAdd(&cntw[g], 1);
+                if (o < 8) lfw[(int64_t)g * 8 + o] = f;
+            }
+        }
+        // the loss: lanes, then waves, in a fixed order
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mine = mine + __shfl_xor(mine, m);
+        if (lane == 0) red[wv] = mine;
+        sy.lds();
+        loss = (red[0] + red[1]) + (red[2] + red[3]);
+        sy.lds();
+        return true;
     }
     static size_t policy_bytes(const DevParams& P, const Args& A) { return ((Base::extra_lds_bytes(P, A) + 15) / 16) * 16; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return policy_bytes(P, A) + sizeof(LocompLds<R>) + 16; }
@@ -192,6 +281,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static constexpr bool kFused = false;
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
+    static constexpr bool kGroupUpdate = false;
     static constexpr int kMinWavesPerSimd = GS;
     static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = false;
@@ -435,6 +525,80 @@ __device__ __forceinline__ void wg_solve(int n, GET get, VGET vget, VSET vset, S
     sy.full();
 }
 
+// ---- the re-fit of a usual group (a handful of independent atoms) entirely in registers ------------------------------------------
+// One wave; lane r < n holds row r of the Gram matrix (G[r][0..r]), lane n the right-hand side as one more row: the column
+// operations of the Cholesky factorisation then leave y = L^-1 b in that lane (the factor of the matrix bordered by b), and the
+// backward substitution walks the rows of L through v_readlane.  Register indices are static (the loops are unrolled to NF with
+// uniform guards), lane indices uniform: no LDS traffic, no wave barrier, no dependent memory round trip -- the LDS form took 84 k
+// (10 atoms) to 237 k (18 atoms) cycles per selection at BASELINE config 5, most of it the single-lane substitutions.
+// No pivoting: a pivot below kLocompFastPivot of its atom's own norm (an ill-conditioned or rank-deficient group) returns false and
+// the group goes through the pivoted, rank-revealing path.  g: packed lower triangle, b: right-hand sides, diag: original diagonal.
+constexpr double kLocompFastPivot = 1e-6;
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int NF>
+__device__ __attribute__((noinline)) bool locomp_fast_solve(const double* g, const double* b, const double* diag, int n_, double* x_out)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    double row[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        double v = 0.0;
+        if (j < n) {
+            if (lane < n && j <= lane) v = g[lane * (lane + 1) / 2 + j];
+            else if (lane == n) v = b[j];
+        }
+        row[j] = v;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        if (j < n && ok) {                                        // uniform
+            const double piv = readlane_f64(row[j], j);
+            if (!(piv > kLocompFastPivot * diag[j])) ok = false;
+            else {
+                const double ljj = sqrt(piv);
+                const double lrj = lane == j ? ljj : row[j] / ljj;
+                if (lane >= j) row[j] = lrj;
+#pragma unroll
+                for (int q = j + 1; q < NF; ++q)
+                    if (q < n) {
+                        const double lqj = readlane_f64(row[j], q);
+                        if (lane >= q) row[q] -= lrj * lqj;
+                    }
+            }
+        }
+    }
+    if (!ok) return false;
+    // L^T x = y: y sits in lane n; x_r = y_r / L[r][r], then y_i -= L[r][i] x_r for the rows in front of r
+#pragma unroll
+    for (int r = NF - 1; r >= 0; --r) {
+        if (r < n) {
+            const double lrr = readlane_f64(row[r], r);
+            const double yr = readlane_f64(row[r], n);
+            const double xr = yr / lrr;
+            if (lane == n) row[r] = xr;
+#pragma unroll
+            for (int i = 0; i < r; ++i) {
+                const double lri = readlane_f64(row[i], r);
+                if (lane == n) row[i] -= lri * xr;
+            }
+        }
+    }
+    if (lane == n) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            if (i < n) x_out[i] = row[i];
+    }
+    return true;
+}
+
 // One selected atom (p, k, c): modeling.py:1314-1383.  All threads of the signal's workgroup; the caller leaves the atom
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
@@ -562,6 +726,34 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     if (i == j) setDg(i, acc);
                 }
             }
+        } else if (nitems <= 4 * kThreads) {
+            // dense dictionary, a usual group: one THREAD per item, a sequential sum over the overlap (the dictionary rows come out of
+            // the L2; 65 items of 32 products at BASELINE config 5 took 44 k cycles as wave-wide reductions)
+            for (int it = tid; it < nitems; it += kThreads) {
+                double acc = 0.0;
+                if (it < n) {
+                    int s_, e_, es_;
+                    const int len = centered_span(T, W, T_(it), s_, e_, es_);
+                    const R* dk = S.D + ((int64_t)K_(it) * W + es_) * F;
+                    const R* rv = G.r + (int64_t)s_ * F;
+                    for (int x = 0; x < len * F; ++x) acc += (double)dk[x] * (double)rv[x];
+                    setB(it, acc);
+                } else {
+                    int i, j;
+                    tri_decode(it - n, i, j);
+                    int si_, ei_, esi, sj_, ej_, esj;
+                    centered_span(T, W, T_(i), si_, ei_, esi);
+                    centered_span(T, W, T_(j), sj_, ej_, esj);
+                    const int lo = max(si_, sj_), hi = min(ei_, ej_);
+                    if (hi > lo) {
+                        const R* di = S.D + ((int64_t)K_(i) * W + (lo - si_ + esi)) * F;
+                        const R* dj = S.D + ((int64_t)K_(j) * W + (lo - sj_ + esj)) * F;
+                        for (int x = 0; x < (hi - lo) * F; ++x) acc += (double)di[x] * (double)dj[x];
+                    }
+                    gs(L.at(i, j), acc);
+                    if (i == j) setDg(i, acc);
+                }
+            }
         } else
         for (int it = wv; it < nitems; it += kWaves) {
             double acc = 0.0;
@@ -606,14 +798,31 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         auto PERM_ = UT_;                                          // pivot of step s            (the free list `ut`)
         auto POS_ = [&](int i) -> int { return bigL ? gld(GG.usi + i) : L.usi[i]; };      // step at which atom i was taken, -1: not (yet)
         auto setPOS = [&](int i, int v) { if (bigL) gst(GG.usi + i, v); else L.usi[i] = v; };
-        int rank;
-        if (!big) {
+        int rank = -1;
+        constexpr int kFast = Pol::Lds::kFastGroup;
+        if (!big && n <= kFast) {                                  // uniform: the usual group, in registers (locomp_fast_solve)
+            if (wv == 0) {
+                // (three unrollings: the guards of the unused steps are what a small group would pay for)
+                bool ok;
+                if (n <= 8) ok = locomp_fast_solve<8>(L.g, L.b, L.diag, n, L.b);
+                else if (kFast >= 16 && n <= 16) ok = locomp_fast_solve<16>(L.g, L.b, L.diag, n, L.b);
+                else ok = locomp_fast_solve<kFast>(L.g, L.b, L.diag, n, L.b);
+                if (lane == 0) L.cnt = ok ? n : -1;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (ok && lane < n) L.a[lane] = (R)L.b[lane];
+            }
+            sy.full();
+            rank = L.cnt;
+        }
+        if (rank >= 0) {
+        } else if (!big) {
             // one wave, lane = atom (n <= 64: the Gram matrix is in LDS)
             if (wv == 0) {
                 int rk = 0;
                 unsigned long long done = 0ull;
                 double dmax0 = 0.0;
-                if (lane < n) L.usi[lane] = -1;
+                if (lane < n) { L.usi[lane] = -1; L.diag[lane] = L.b[lane]; }       // (diag: the right-hand side under elimination)
                 for (int s_ = 0; s_ < n; ++s_) {
                     double v = (lane < n && !((done >> lane) & 1ull)) ? L.g[L.at(lane, lane)] : -1.0;
                     int idx = lane;
@@ -622,11 +831,12 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     if (!(v > kLocompRankTol * dmax0)) break;                     // uniform
                     const int pp = idx;
                     const double ljj = sqrt(v);
-                    if (lane == 0) { L.g[L.at(pp, pp)] = ljj; L.ut[s_] = pp; L.usi[pp] = s_; }
+                    const double ys = L.diag[pp] / ljj;                           // y of this step (L y = b, row by row as L appears)
+                    if (lane == 0) { L.g[L.at(pp, pp)] = ljj; L.ut[s_] = pp; L.usi[pp] = s_; L.diag[pp] = ys; }
                     done |= 1ull << pp;
                     const bool mine = lane < n && !((done >> lane) & 1ull);
                     double lrp = 0.0;
-                    if (mine) { lrp = L.g[sym(lane, pp)] / ljj; L.g[sym(lane, pp)] = lrp; }
+                    if (mine) { lrp = L.g[sym(lane, pp)] / ljj; L.g[sym(lane, pp)] = lrp; L.diag[lane] -= lrp * ys; }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (mine)
@@ -636,23 +846,17 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     ++rk;
                 }
-                if (lane == 0) {
-                    L.cnt = rk;
-                    if (rk == n) {
-                        // forward (L y = b), then backward (L^T z = y), in pivot order; x[perm[s]] = z[s]
-                        for (int i = 0; i < n; ++i) {
-                            const int pi = L.ut[i];
-                            double v = L.b[pi];
-                            for (int q = 0; q < i; ++q) v -= L.g[sym(pi, L.ut[q])] * L.diag[q];
-                            L.diag[i] = v / L.g[L.at(pi, pi)];
-                        }
-                        for (int i = n - 1; i >= 0; --i) {
-                            const int pi = L.ut[i];
-                            double v = L.diag[i];
-                            for (int q = i + 1; q < n; ++q) v -= L.g[sym(L.ut[q], pi)] * L.diag[q];
-                            L.diag[i] = v / L.g[L.at(pi, pi)];
-                        }
-                        for (int i = 0; i < n; ++i) { const int pi = L.ut[i]; L.b[pi] = L.diag[i]; L.a[pi] = (R)L.diag[i]; }
+                if (lane == 0) L.cnt = rk;
+                if (rk == n) {
+                    // backward (L^T z = y) in pivot order, the atoms taken before step s in parallel; x[perm[s]] = z[s]
+                    const int mypos = lane < n ? L.usi[lane] : 0x7fffffff;
+                    for (int s_ = n - 1; s_ >= 0; --s_) {
+                        const int p2 = L.ut[s_];
+                        const double z = L.diag[p2] / L.g[L.at(p2, p2)];
+                        if (mypos < s_) L.diag[lane] -= L.g[sym(p2, lane)] * z;
+                        if (lane == 0) { L.b[p2] = z; L.a[p2] = (R)z; }
+                        __builtin_amdgcn_wave_barrier();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                 }
             }
@@ -743,10 +947,14 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     }
 
     // ---- :1336-1341 / :1345-1350 coefficients += fitted; residual -= fitted * atom, with the local energies (:996-1016)
-    auto book = [&](int gi, int tp, int kk, R cf) {                      // (one thread)
+    // the coefficient slots of the group, all atoms side by side (only the selected atom can be new to the list; it alone leaves an
+    // event); nnz counts stored non-zeros (:1368)
+    for (int gi = tid; gi < n; gi += kThreads) {
+        const int tp = T_(gi), kk = K_(gi);
+        const R cf = A_(gi);
         int si = SI_(gi);
         double before = 0.0;
-        if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }
+        if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }        // (gi == 0 only)
         else before = G.slot_a[si];
         const double after = before + (double)cf;
         G.slot_a[si] = after;
@@ -755,18 +963,26 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             const int ev = sh.nev++;
             G.ev_t[ev] = tp; G.ev_k[ev] = kk; G.ev_c[ev] = c;
         }
-        sh.nnz += (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
-    };
+        const int d = (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
+        if (d) atomicAdd(&sh.nnz, d);
+    }
+    // A policy that knows the cells of its atoms (sparse dictionary, row lists) applies the whole group in one pass
+    bool grouped = false;
+    if constexpr (Pol::kGroupUpdate) {
+        R gloss = (R)0;
+        grouped = Pol::group_update(P, G, A, plds, n, T_, K_, A_, gloss, sh.red, sy);        // uniform
+        if (grouped && tid == 0) L.loss = L.loss + gloss;
+    }
     // Short atoms (a few elements per lane): the whole group by ONE wave, atom after atom, without a workgroup barrier per
     // atom.  Lane l carries the four strided partial sums l, 64+l, 128+l, 192+l of the workgroup form (wave_window_energy):
     // the same trees, the same bits.
     const bool wave_apply = Pol::kWaveApply && W * F <= 1024;            // uniform
-    if (wave_apply) {
+    if (grouped) sy.full();
+    else if (wave_apply) {
         if (wv == 0)
             for (int gi = 0; gi < n; ++gi) {
                 const int tp = T_(gi), kk = K_(gi);
                 const R cf = A_(gi);
-                if (lane == 0) book(gi, tp, kk, cf);
                 int s, e, es;
                 const int cnt = centered_span(T, W, tp, s, e, es) * F;
                 const R nc = -cf;
@@ -812,7 +1028,6 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     for (int gi = 0; gi < n; ++gi) {
         const int tp = T_(gi), kk = K_(gi);
         const R cf = A_(gi);
-        if (tid == 0) book(gi, tp, kk, cf);
         int s, e, es;
         const int len = centered_span(T, W, tp, s, e, es);
         R pb = (R)0, pa = (R)0;
