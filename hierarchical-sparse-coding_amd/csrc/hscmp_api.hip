@@ -426,7 +426,7 @@ static int ensure_workspace_g(hscmp_ctx* ctx, const DevParams& P, bool need_x, s
         {(void**)&ctx->d_rl_f, &ctx->cap_rl_f, row_lists ? B * T * kRowListCap * sizeof(int) : 0},
         {(void**)&ctx->d_hkey, &ctx->cap_hkey, B * ((size_t)P.hmask + 1) * sizeof(unsigned long long)},
         {(void**)&ctx->d_hval, &ctx->cap_hval, B * ((size_t)P.hmask + 1) * sizeof(int)},
-        {(void**)&ctx->d_head, &ctx->cap_head, P.blocked ? B * T * sizeof(int) : 0},
+        {(void**)&ctx->d_head, &ctx->cap_head, (P.blocked || ctx->method == HSCMP_METHOD_LOCOMP) ? B * T * sizeof(int) : 0},
         {(void**)&ctx->d_lgram, &ctx->cap_lgram, ctx->method == HSCMP_METHOD_LOCOMP ? B * lgram_doubles(P.lg_cap) * sizeof(double) : 0},
     };
     bool stream_idle = false;

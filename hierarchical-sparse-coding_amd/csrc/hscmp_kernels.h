@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
     G.slot_t = S.slot_t + (int64_t)b * P.cap; G.slot_k = S.slot_k + (int64_t)b * P.cap; G.slot_a = S.slot_a + (int64_t)b * P.cap;
     G.hkey = S.hkey + (int64_t)b * ((int64_t)P.hmask + 1); G.hval = S.hval + (int64_t)b * ((int64_t)P.hmask + 1);
     G.sel_t = S.sel_t + (int64_t)b * 2 * P.maxsel; G.sel_k = S.sel_k + (int64_t)b * 2 * P.maxsel; G.sel_c = S.sel_c + (int64_t)b * 2 * P.maxsel;
-    G.head = S.head;
+    G.head = (Recorr::kLocomp && S.head) ? S.head + (int64_t)b * T : S.head;
     G.lgram = S.lgram ? S.lgram + (int64_t)b * (int64_t)lgram_doubles(P.lg_cap) : nullptr;
 #ifdef HSCMP_DBG_STAMPS
     if (tid == 0 && b < 4096) {
@@ -1023,6 +1023,15 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         sh.converged = 0; sh.stop = STOP_RUNNING; sh.nsel = 0; sh.skip = 0; sh.found = -1; sh.nullsel = 0; sh.hashed = 0; sh.fpos = 0;
         sh.e_sig = S.energy[2 * b + 0]; sh.e_res = S.energy[2 * b + 1];
         sh.ctl[0] = 0; sh.ctl[1] = sh.nev; sh.ctl[2] = sh.nslots; sh.ctl[3] = 0;
+    }
+    if constexpr (Recorr::kLocomp) {
+        // LoCOMP: the coefficient slots chained by position (head[t] -> most recent slot, hval[slot] -> the one before): its
+        // neighbourhood search walks them (hscmp_locomp.h).  Rebuilt on every launch from the slot list, like the Bloom filter below.
+        for (int i = tid; i < T; i += kThreads) hval_store(G.head + i, -1);
+        sy.full();
+        const int ns = stats[ST_SLOTS];
+        for (int i = tid; i < ns; i += kThreads)
+            hval_store(G.hval + i, __hip_atomic_exchange(G.head + G.slot_t[i], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     if constexpr (!Recorr::kFused) {
         for (int i = tid; i < (Recorr::kMaxSegments + 31) / 32; i += kThreads) sh.touched[i] = 0u;

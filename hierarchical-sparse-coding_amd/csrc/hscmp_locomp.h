@@ -621,15 +621,19 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     centered_span(T, W, p, s0, e0, es0);
     const int nstart = max(s0 - W / 2, 0);
     const int nend = min((e0 - 1) + ((W & 1) ? W / 2 : W / 2 - 1), T);
-    const int ns = sh.nslots;
-    for (int i = tid; i < ns; i += kThreads) {
-        const int ti = G.slot_t[i], ki = G.slot_k[i];
-        if (ti == p && ki == k) L.si[0] = i;                     // (at most one)
-        if (ti < nstart || ti > nend || ki == k || (ti - nstart) == p) continue;
-        if (!(G.slot_a[i] != 0.0)) continue;                      // (the list-of-lists matrix drops an entry that became 0.0)
-        const int o = atomicAdd(&L.cnt, 1);
-        if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
-    }
+    // the coefficient slots of a position are chained (head[t]: the most recent one, hval[slot]: the one before it; iterate_kernel's
+    // prologue builds the chains, the bookkeeping below extends them): the neighbourhood is a walk over the chains of its 2W + 1
+    // positions, one thread each, instead of a scan of the whole slot list (14 k slots per signal at BASELINE config 5)
+    const int nlast = min(nend, T - 1);
+    for (int ti = nstart + tid; ti <= nlast; ti += kThreads)
+        for (int i = hval_load(G.head + ti); i >= 0; i = hval_load(G.hval + i)) {
+            const int ki = G.slot_k[i];
+            if (ti == p && ki == k) L.si[0] = i;                 // (at most one)
+            if (ki == k || (ti - nstart) == p) continue;
+            if (!(G.slot_a[i] != 0.0)) continue;                  // (the list-of-lists matrix drops an entry that became 0.0)
+            const int o = atomicAdd(&L.cnt, 1);
+            if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
+        }
     sy.full();
     HSCMP_STAMP(0);                                              // neighbourhood scan
     const int m = L.cnt;
@@ -644,13 +648,14 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         sy.full();                                               // (everybody has read the count)
         if (tid == 0) L.cnt = 0;
         sy.full();
-        for (int i = tid; i < ns; i += kThreads) {
-            const int ti = G.slot_t[i], ki = G.slot_k[i];
-            if (ti < nstart || ti > nend || ki == k || (ti - nstart) == p) continue;
-            if (!(G.slot_a[i] != 0.0)) continue;
-            const int o = atomicAdd(&L.cnt, 1);
-            gst(GG.ut + o, ti); gst(GG.uk + o, ki); gst(GG.usi + o, i);
-        }
+        for (int ti = nstart + tid; ti <= nlast; ti += kThreads)
+            for (int i = hval_load(G.head + ti); i >= 0; i = hval_load(G.hval + i)) {
+                const int ki = G.slot_k[i];
+                if (ki == k || (ti - nstart) == p) continue;
+                if (!(G.slot_a[i] != 0.0)) continue;
+                const int o = atomicAdd(&L.cnt, 1);
+                gst(GG.ut + o, ti); gst(GG.uk + o, ki); gst(GG.usi + o, i);
+            }
         sy.full();
     }
     auto T_ = [&](int i) -> int { return bigL ? gld(GG.t + i) : L.t[i]; };
@@ -685,7 +690,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     const int n = 1 + m;
     HSCMP_STAMP(1);                                              // group order
 #ifdef HSCMP_DBG_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[14] += 1; g_stamps[15] += (unsigned long long)n; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[14] += 1; g_stamps[15] += (unsigned long long)n; g_stamps[16 + min(n >> 3, 15)] += 1; }
 #endif
 
     // the Gram matrix: in LDS, or -- a group larger than the policy keeps there -- in the signal's global scratch (through L2)
@@ -727,19 +732,20 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                 }
             }
         } else if (nitems <= 4 * kThreads) {
-            // dense dictionary, a usual group: one THREAD per item, a sequential sum over the overlap (the dictionary rows come out of
-            // the L2; 65 items of 32 products at BASELINE config 5 took 44 k cycles as wave-wide reductions)
-            for (int it = tid; it < nitems; it += kThreads) {
+            // dense dictionary, a usual group: EIGHT LANES per item (32 items per pass), each a strided share of the overlap, three
+            // exchange steps -- a wave per item left 56 lanes idle on a 9-item group and made 65 items sixteen passes; a thread per
+            // item made every sum a chain of 64 dependent loads
+            for (int it = tid >> 3; it < nitems; it += kThreads >> 3) {
+                const int sub = tid & 7;
                 double acc = 0.0;
+                int i = 0, j = 0;
                 if (it < n) {
                     int s_, e_, es_;
                     const int len = centered_span(T, W, T_(it), s_, e_, es_);
                     const R* dk = S.D + ((int64_t)K_(it) * W + es_) * F;
                     const R* rv = G.r + (int64_t)s_ * F;
-                    for (int x = 0; x < len * F; ++x) acc += (double)dk[x] * (double)rv[x];
-                    setB(it, acc);
+                    for (int x = sub; x < len * F; x += 8) acc += (double)dk[x] * (double)rv[x];
                 } else {
-                    int i, j;
                     tri_decode(it - n, i, j);
                     int si_, ei_, esi, sj_, ej_, esj;
                     centered_span(T, W, T_(i), si_, ei_, esi);
@@ -748,10 +754,13 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     if (hi > lo) {
                         const R* di = S.D + ((int64_t)K_(i) * W + (lo - si_ + esi)) * F;
                         const R* dj = S.D + ((int64_t)K_(j) * W + (lo - sj_ + esj)) * F;
-                        for (int x = 0; x < (hi - lo) * F; ++x) acc += (double)di[x] * (double)dj[x];
+                        for (int x = sub; x < (hi - lo) * F; x += 8) acc += (double)di[x] * (double)dj[x];
                     }
-                    gs(L.at(i, j), acc);
-                    if (i == j) setDg(i, acc);
+                }
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+                if (sub == 0) {
+                    if (it < n) setB(it, acc);
+                    else { gs(L.at(i, j), acc); if (i == j) setDg(i, acc); }
                 }
             }
         } else
@@ -822,6 +831,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                 int rk = 0;
                 unsigned long long done = 0ull;
                 double dmax0 = 0.0;
+                double* col = reinterpret_cast<double*>(L.uk);           // (the free list `uk` and what follows it: NMAX ints = 64 doubles)
                 if (lane < n) { L.usi[lane] = -1; L.diag[lane] = L.b[lane]; }       // (diag: the right-hand side under elimination)
                 for (int s_ = 0; s_ < n; ++s_) {
                     double v = (lane < n && !((done >> lane) & 1ull)) ? L.g[L.at(lane, lane)] : -1.0;
@@ -837,11 +847,15 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
                     const bool mine = lane < n && !((done >> lane) & 1ull);
                     double lrp = 0.0;
                     if (mine) { lrp = L.g[sym(lane, pp)] / ljj; L.g[sym(lane, pp)] = lrp; L.diag[lane] -= lrp * ys; }
+                    // the scaled column as a compact array (0 for the atoms already taken: their entries of a row hold L and must
+                    // stay -- x - l * 0 leaves them as they are), so that the trailing update of a row is one branch-free sweep
+                    if (lane < n) col[lane] = lrp;
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (mine)
-                        for (int q = 0; q <= lane; ++q)
-                            if (!((done >> q) & 1ull)) L.g[L.at(lane, q)] -= lrp * L.g[sym(q, pp)];
+                    if (mine) {
+                        double* rowp = L.g + L.at(lane, 0);
+                        for (int q = 0; q <= lane; ++q) rowp[q] -= lrp * col[q];
+                    }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     ++rk;
@@ -954,7 +968,10 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         const R cf = A_(gi);
         int si = SI_(gi);
         double before = 0.0;
-        if (si < 0) { si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk; }        // (gi == 0 only)
+        if (si < 0) {                                                                   // (gi == 0 only)
+            si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk;
+            hval_store(G.hval + si, hval_load(G.head + tp)); hval_store(G.head + tp, si);       // the new head of its position's chain
+        }
         else before = G.slot_a[si];
         const double after = before + (double)cf;
         G.slot_a[si] = after;
