@@ -293,3 +293,83 @@ def test_config5_generated_three_level_dictionary(monkeypatch):
         for l in range(3):
             assert (scipy.sparse.csc_matrix(coefs[b][l]) != scipy.sparse.csc_matrix(coefs2[b][l])).nnz == 0, (b, l)
     gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method', ['cmp', 'locomp'])
+def test_config4_dims_several_chunks_through_the_device_epilogue(method):
+    """The memory-budget path that anything larger than config 4 takes by default: levels >= 1 walk the batch in chunks (their dense
+    float64 input [T, 256] lives on the device: 16.8 MB per signal here, 134 MB at T = 65536), every chunk through the device epilogue.
+    A budget that holds 7 of the 20 signals => three chunks (7 + 7 + 6); the result must equal the one-chunk run bit for bit --
+    coefficient matrices, event records, residual samples and device-summed residual energies -- for both methods."""
+    import hsc_amd.synth as synth
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    B, T, W1 = 20, 8192, 17
+    mld, mlds = _hierarchy(W1)
+    xs = synth.make_hierarchy_batch(mld, T, 0, B, seed=4)
+    h = HierarchicalConvolutionalMatchingPursuit(method=method)
+    try:
+        one = h.computeCoefficientsBatch(xs, mlds, returnEvents=True, **HSC_KW)
+        assert one[2][1]['chunks'] == 1
+        # the budget of 7 signals, by the pipeline's own estimate (_LevelPipeline.chunk_size; tests/test_hierarchical.py pins it)
+        per_signal = 1.05 * T * 256 * 8 + 160 * T + 80.0 * 4096
+        budget = 7.5 * per_signal
+        many = h.computeCoefficientsBatch(xs, mlds, returnEvents=True, memoryBudget=budget, **HSC_KW)
+        assert many[2][1]['chunks'] == 3, many[2][1]
+        energy = h.computeCoefficientsBatch(xs, mlds, residuals='energy', memoryBudget=budget, **HSC_KW)
+        assert energy[2][1]['chunks'] == 3
+    finally:
+        h.close()
+    assert np.array_equal(one[1], many[1])
+    assert np.allclose(energy[1], np.sum(np.square(one[1]), axis=1), rtol=1e-12, atol=0.0)
+    for b in range(B):
+        assert np.array_equal(one[3][b], many[3][b]), b
+        for l in range(2):
+            assert (scipy.sparse.csc_matrix(one[0][b][l]) != scipy.sparse.csc_matrix(many[0][b][l])).nnz == 0, (b, l)
+            assert (scipy.sparse.csc_matrix(one[0][b][l]) != scipy.sparse.csc_matrix(energy[0][b][l])).nnz == 0, (b, l)
+
+
+@pytest.mark.gpu
+def test_config4_full_length_signals_level0_vs_oracle_level1_vs_dense_input():
+    """BASELINE configs[3] at its FULL signal length (T = 65536, 17 taps), 32 signals.  The oracle cannot run the dense level-1
+    correlation at this size (219 GFLOP per signal), so the levels are pinned separately: level 0 of two signals against the CPU oracle,
+    bit for bit (positions, atoms, coefficients, residual); level 1 of the same two signals -- device-chained: the input scattered from
+    the level-0 slots in GPU memory -- against the single-level engine run on the DENSE [T, 256] float64 input the host builds from the
+    level-0 matrix (the path the T = 8192 oracle tests pin), bit for bit; every signal: reconstruction SNR and the device energies."""
+    import hsc_amd.synth as synth
+    from oracle import hsc_oracle as orc
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit
+    from hsc_amd.modeling import ConvolutionalMatchingPursuit
+    B, T, W1 = 32, 65536, 17
+    mld, mlds = _hierarchy(W1)
+    xs = synth.make_hierarchy_batch(mld, T, 0, B, seed=4)
+    h = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    try:
+        raw, residuals, timings = h.computeCoefficientsBatch(xs, mlds, returnDistributed=False, epilogue='host', **HSC_KW)     # (level matrices as encoded)
+        coefs, energies, _ = h.computeCoefficientsBatch(xs, mlds, residuals='energy', **HSC_KW)
+    finally:
+        h.close()
+    D0, D1 = mlds.getRawDictionary(0), mlds.getRawDictionary(1)
+    w1 = np.ones(D1.shape[0], dtype=D1.dtype); w1[:D1.shape[0] - mlds.countsNoSingletons[1]] = HSC_KW['singletonWeight']
+    first = HierarchicalConvolutionalMatchingPursuit(method='cmp')
+    try:
+        lvl0, _, _ = first.computeCoefficientsBatch(xs[[3, 29]], _first_level_only(mlds), toleranceSnr=[HSC_KW['toleranceSnr'][0]], nbBlocks=HSC_KW['nbBlocks'],
+                                                    singletonWeight=HSC_KW['singletonWeight'], returnDistributed=False)
+    finally:
+        first.close()
+    for j, b in enumerate((3, 29)):
+        c0, r0, info = orc.cmp_encode(xs[b], D0, toleranceSnr=HSC_KW['toleranceSnr'][0], nbBlocks=HSC_KW['nbBlocks'],
+                                      weights=np.ones(D0.shape[0], dtype=D0.dtype))
+        assert (scipy.sparse.csc_matrix(lvl0[j][0]) != c0).nnz == 0, b
+        dense = np.asarray(c0.toarray(), dtype=np.float64)
+        res1 = ConvolutionalMatchingPursuit().computeCoefficientsBatch(dense[None], D1, toleranceSnr=HSC_KW['toleranceSnr'][1], nbBlocks=HSC_KW['nbBlocks'], weights=w1)
+        assert (scipy.sparse.csc_matrix(raw[b][1]) != res1.coefficients[0]).nnz == 0, b
+    snr = 10 * np.log10(np.sum(xs.astype(np.float64) ** 2, axis=1) / energies)
+    assert np.all(snr >= 25.0), snr.min()
+    # (the non-distributed host-epilogue run sums the same atoms from the last level's matrix alone: the same residual up to summation order)
+    assert np.allclose(energies, np.sum(np.square(residuals), axis=1), rtol=1e-6, atol=0.0)
+
+
+def _first_level_only(mlds):
+    from hsc_amd.dataset import MultilevelDictionary
+    return MultilevelDictionary.fromRawDictionaries([mlds.getRawDictionary(0)], [int(mlds.scales[0])])

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import os
-N_CASES = int(os.environ.get("HSCMP_FUZZ_CASES", "320"))
+N_CASES = int(os.environ.get("HSCMP_FUZZ_CASES", "1600"))
 OFFSET = int(os.environ.get("HSCMP_FUZZ_OFFSET", "0"))           # soak runs explore other seeds
 
 
@@ -146,7 +146,7 @@ def test_random_configuration_vs_oracle(i):
         assert np.array_equal(t3, info3['t']) and np.array_equal(k3, info3['k']) and np.array_equal(c3, info3['c']), (tag, 'callback', nrounds)
 
 
-N_BATCHES = int(os.environ.get("HSCMP_FUZZ_BATCHES", "48"))
+N_BATCHES = int(os.environ.get("HSCMP_FUZZ_BATCHES", "160"))
 
 
 @pytest.mark.parametrize('i', range(N_BATCHES))
@@ -175,7 +175,7 @@ def test_random_batch_vs_oracle(i):
         assert res.stop_reasons()[b] == info['stop'], tag
 
 
-N_EDGE = int(os.environ.get("HSCMP_FUZZ_EDGE", "24"))
+N_EDGE = int(os.environ.get("HSCMP_FUZZ_EDGE", "120"))
 
 
 @pytest.mark.parametrize('i', range(N_EDGE))
@@ -216,7 +216,7 @@ def test_medium_signals_with_atoms_piled_at_the_edges(i):
     assert cmp.lastResult.stop_reasons()[0] == info['stop'], tag
 
 
-N_LEVEL = int(os.environ.get("HSCMP_FUZZ_LEVEL", "6"))
+N_LEVEL = int(os.environ.get("HSCMP_FUZZ_LEVEL", "24"))
 
 
 @pytest.mark.parametrize('i', range(N_LEVEL))

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N = int(os.environ.get('HSCMP_FUZZ_ENTRY', '40'))
+N = int(os.environ.get('HSCMP_FUZZ_ENTRY', '160'))
 
 
 def _shape(i):

@@ -201,7 +201,7 @@ def test_hierarchical_medium_generated_data_vs_reference(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed', range(int(os.environ.get('HSCMP_FUZZ_HSC', '8'))))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('HSCMP_FUZZ_HSC', '24'))))
 def test_hierarchical_random_generated_cases_gpu_equals_oracle_level_coder(seed, monkeypatch):
     """Random generated dictionaries / signals / parameters: the GPU hierarchical encoder (per-signal path and the
     device-chained batch path) against the same host logic driven by the CPU oracle as its level coder -- bit for
@@ -437,3 +437,88 @@ def test_level_input_buffer_is_clean_for_the_next_batch(case, monkeypatch):
             for l in range(len(exp[b])):
                 assert (scipy.sparse.csc_matrix(got[b][l]) != scipy.sparse.csc_matrix(exp[b][l])).nnz == 0, (b, l)
     warm.close(); fresh.close()
+
+
+# ---- the level pipeline object (hierarchical._LevelPipeline), step by step on the CPU ------------------------------------------
+
+class _FakeEngine(object):
+    def __init__(self, total=100e9):
+        self.total = total
+        self.copied = []
+
+    def mem_info(self):
+        return (self.total, self.total)
+
+    def copy_from_device(self, ptr, shape, dtype):
+        self.copied.append((int(ptr), tuple(shape), np.dtype(dtype)))
+        return np.full(shape, 7, dtype=dtype)
+
+
+def _pipeline(xs, **over):
+    from hsc_amd.hierarchical import HierarchicalConvolutionalMatchingPursuit, _LevelPipeline
+    mld = _mld().withSingletonBases()
+    kw = dict(toleranceSnr=[10.0, 20.0, 30.0], nbBlocks=4, singletonWeight=0.25, returnDistributed=True, epilogue='device', returnEvents=False,
+              deviceInput=None, residuals='samples', memoryBudget=None)
+    kw.update(over)
+    return _LevelPipeline(HierarchicalConvolutionalMatchingPursuit(method='cmp'), xs, mld, kw['toleranceSnr'], kw['nbBlocks'], kw['singletonWeight'],
+                          kw['returnDistributed'], kw['epilogue'], kw['returnEvents'], kw['deviceInput'], kw['residuals'], kw['memoryBudget']), mld
+
+
+def test_pipeline_level_setup_weights_and_targets():
+    """:1439-1450: per-level SNR target (list or scalar), singletonWeight on the first K_l - countsNoSingletons[l] atoms, eps of the
+    dictionary's dtype."""
+    xs = np.zeros((3, 512), dtype=np.float32)
+    pipe, mld = _pipeline(xs)
+    for level in range(3):
+        D, w, snr, eps = pipe.level_setup(level)
+        ns = D.shape[0] - mld.countsNoSingletons[level]
+        assert snr == [10.0, 20.0, 30.0][level] and eps == float(np.finfo(D.dtype).eps)
+        assert np.all(w[:ns] == 0.25) and np.all(w[ns:] == 1.0) and w.dtype == D.dtype
+    pipe, _ = _pipeline(xs, toleranceSnr=12.5)
+    assert [pipe.level_setup(l)[2] for l in range(3)] == [12.5] * 3
+
+
+def test_pipeline_chunk_size_follows_the_memory_budget():
+    from hsc_amd import _native
+    xs = np.zeros((40, 512), dtype=np.float32)
+    pipe, mld = _pipeline(xs)
+    pipe.engines = [_FakeEngine(total=10e6)]
+    setups = [None] + [pipe.level_setup(l) for l in (1, 2)]
+    stats0 = np.zeros((40, _native.STAT_COUNT), dtype=np.int32)
+    stats0[:, _native.STAT_SLOTS] = 50
+    per_signal = sum(1.05 * 512 * setups[l][0].shape[2] * 8 + 160 * 512 + 80.0 * 4096 for l in (1, 2))
+    assert pipe.chunk_size(setups, stats0) == int(0.6 * 10e6 // per_signal)        # default: 60 % of the GPU
+    pipe.memoryBudget = 3.5 * per_signal
+    assert pipe.chunk_size(setups, stats0) == 3
+    pipe.memoryBudget = 1.0
+    assert pipe.chunk_size(setups, stats0) == 1                                     # never below one signal
+    pipe.memoryBudget = 1e15
+    assert pipe.chunk_size(setups, stats0) == 40                                    # never beyond the batch
+    stats0[:, _native.STAT_SLOTS] = 100000                                          # long slot lists count too
+    pipe.memoryBudget = 3.5 * per_signal
+    assert pipe.chunk_size(setups, stats0) < 3
+
+
+def test_pipeline_host_signal_reads_the_device_when_the_batch_came_as_a_pointer():
+    """with deviceInput the host array is a placeholder (shape and dtype only); whatever falls back to the host must copy the
+    signal from the device."""
+    xs = np.zeros((5, 512), dtype=np.float32)
+    pipe, _ = _pipeline(xs, deviceInput=4096)
+    eng = _FakeEngine()
+    pipe.engines, pipe.dt0 = [eng], np.float32
+    got = pipe.host_signal(3)
+    assert eng.copied == [(4096 + 3 * 512 * 4, (512,), np.dtype(np.float32))] and np.all(got == 7)
+    pipe, _ = _pipeline(np.arange(10, dtype=np.float32).reshape((2, 5)))
+    assert np.array_equal(pipe.host_signal(1), [5, 6, 7, 8, 9])                     # host batch: the row itself
+
+
+def test_pipeline_capacity_hint_and_regrowth_bound():
+    from hsc_amd import _native
+    xs = np.zeros((2, 512), dtype=np.float32)
+    pipe, _ = _pipeline(xs)
+    eng = _FakeEngine()
+    assert pipe.start_capacity(eng, 4096) == 4096
+    eng._capacity_hint = ((512, 4), 20000)
+    assert pipe.start_capacity(eng, 4096) == min(20000, _native.max_event_capacity(512))
+    eng._capacity_hint = ((1024, 4), 20000)                                        # another shape: no hint
+    assert pipe.start_capacity(eng, 4096) == 4096
