@@ -57,6 +57,7 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;            // (no per-policy residual update: short atoms go through one wave)
     static constexpr bool kGroupUpdate = false;
+    static constexpr int kFastGroup = LocompLds<R>::kFastGroup;
     static constexpr bool kUnionRows = false;
     static constexpr bool kOwnInit = false;
     static constexpr int kMaxGroup = kLocompMax;
@@ -82,6 +83,8 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
 template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     static constexpr bool kLocomp = true;
     static constexpr int kMinWavesPerSimd = 2;          // (two workgroups per CU: the register-resident re-fit must not cost the second one)
+    static constexpr int kFastGroup = 63;               // (the third level of BASELINE config 5 re-fits 30-60 atoms in one selection out of six:
+                                                        //  this policy has the registers for the whole LDS-resident range; lane n holds b)
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = true;
     static constexpr int kMaxGroup = kLocompMax;
@@ -282,6 +285,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static constexpr bool kLocomp = true;
     static constexpr bool kWaveApply = true;
     static constexpr bool kGroupUpdate = false;
+    static constexpr int kFastGroup = Lds::kFastGroup;
     static constexpr int kMinWavesPerSimd = GS;
     static constexpr int kEnergyWaves = kWaves;
     static constexpr bool kScoreOnly = false;
@@ -808,13 +812,14 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         auto POS_ = [&](int i) -> int { return bigL ? gld(GG.usi + i) : L.usi[i]; };      // step at which atom i was taken, -1: not (yet)
         auto setPOS = [&](int i, int v) { if (bigL) gst(GG.usi + i, v); else L.usi[i] = v; };
         int rank = -1;
-        constexpr int kFast = Pol::Lds::kFastGroup;
+        constexpr int kFast = Pol::kFastGroup;
         if (!big && n <= kFast) {                                  // uniform: the usual group, in registers (locomp_fast_solve)
             if (wv == 0) {
                 // (three unrollings: the guards of the unused steps are what a small group would pay for)
                 bool ok;
                 if (n <= 8) ok = locomp_fast_solve<8>(L.g, L.b, L.diag, n, L.b);
                 else if (kFast >= 16 && n <= 16) ok = locomp_fast_solve<16>(L.g, L.b, L.diag, n, L.b);
+                else if (kFast > 32 && n <= 32) ok = locomp_fast_solve<32>(L.g, L.b, L.diag, n, L.b);
                 else ok = locomp_fast_solve<kFast>(L.g, L.b, L.diag, n, L.b);
                 if (lane == 0) L.cnt = ok ? n : -1;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
