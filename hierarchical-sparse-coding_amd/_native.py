@@ -18,8 +18,9 @@ F32, F64 = 0, 1
 STAT_NNZ, STAT_DUPLICATES, STAT_ROUNDS, STAT_STOP, STAT_ITERATIONS, STAT_EVENTS, STAT_SLOTS, STAT_OFFSET = range(8)
 STAT_COUNT = 8
 STOP_NAMES = {0: 'running', 1: 'energy_eps', 2: 'nnz', 3: 'snr', 4: 'residual_scale', 5: 'empty',
-              6: 'callback', 7: 'capacity', 8: 'stalled', 9: 'group'}
+              6: 'callback', 7: 'capacity', 8: 'stalled', 9: 'group', 100: 'host'}
 STOP_RUNNING, STOP_CAPACITY, STOP_STALLED, STOP_GROUP = 0, 7, 8, 9
+STOP_HOST = 100      # (host side only: the device loop gave the signal up -- stop reason 'group' -- and the host loop finished it)
 METHOD_CMP, METHOD_LOCOMP = 0, 1
 
 # every symbol include/hscmp.h declares (checked by tests/test_abi.py)

@@ -118,6 +118,16 @@ class LoCOMP(ConvolutionalMatchingPursuit):
                                                            nbBlocks, minCoefficients, weights, None)
             res.coefficients[b] = coef
             res.residuals[b] = residual
+            # what describes the signal now is the host loop's run, not the device run that was given up: counters the host loop
+            # can answer are refreshed, the others cleared, the stop reason says who finished the signal
+            if res.stats is not None:
+                res.stats[b, :] = 0
+                res.stats[b, _native.STAT_NNZ] = coef.nnz
+                res.stats[b, _native.STAT_STOP] = _native.STOP_HOST
+            if res.energies is not None:
+                res.energies[b, 1] = float(np.sum(np.square(np.asarray(residual, dtype=np.float64))))
+            if res.events is not None:
+                res.events[b] = (np.zeros((0,), np.int32), np.zeros((0,), np.int32), np.zeros((0,), res.events[b][2].dtype))
         return res
 
     def _batch_on_host(self, sequences, D, *args):
