@@ -348,8 +348,7 @@ def bench_cmp(args, ctx):
     # summary does not cover this shape
     traffic, hbm_fraction, pmc_src, pmc_stale = None, None, None, None
     try:
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
-        from csrc_digest import load_pmc_summary
+        from tools_csrc_digest import load_pmc_summary
         pmc, pmc_stale = load_pmc_summary(os.path.join(ROOT, 'profiles', 'pmc_summary.json'))
         # (a summary collected on other kernels than this tree's is not reported: traffic = null, pmc_stale = true)
         if pmc is not None and not pmc_stale and cfg['B'] == 1024 and cfg['T'] == 65536 and variant.startswith('mfma') and args.dtype == 'f32':

@@ -259,8 +259,7 @@ def run(args, ctx):
             e.update(level_roofline(Dl, T, B, tm, nbBlocks=kw['nbBlocks']))
         levels.append(e)
     # PMC traffic figures only from a summary collected on THIS tree's kernels (tools/csrc_digest.py stamps it)
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    from csrc_digest import load_pmc_summary
+    from tools_csrc_digest import load_pmc_summary
     pmc, pmc_stale = load_pmc_summary(os.path.join(ROOT, 'profiles', 'pmc_summary_hsc%d%s.json' % (config, '_locomp' if getattr(args, 'method', 'cmp') == 'locomp' else '')))
     if pmc_stale:
         pmc = None

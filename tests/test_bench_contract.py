@@ -76,3 +76,17 @@ def test_default_line_carries_the_hierarchical_configurations():
     assert sec['config4_17taps_locomp']['output_check']['reconstructs'] is True
     assert sec['config4_17taps_locomp']['ms_per_step'] <= 3.0 * sec['config4_17taps']['ms_per_step']
     assert sec['config4_16taps']['output_check']['reconstructs'] is None          # (the reference itself reaches 2.9 dB on that hierarchy)
+
+
+def test_no_tools_script_shadows_a_root_module():
+    """tools/ holds stand-alone scripts; some of them put tools/ on sys.path.  A script there named like a root module (bench_hsc.py
+    once was) would be imported in its place -- bench.py's secondary section lost `bench_hsc.compact` that way."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    top = {f for f in os.listdir(root) if f.endswith('.py')}
+    tools = {f for f in os.listdir(os.path.join(root, 'tools')) if f.endswith('.py')}
+    assert not (top & tools), top & tools
+    import bench_hsc
+    assert callable(bench_hsc.compact) and callable(bench_hsc.run)
+    import tools_csrc_digest
+    assert len(tools_csrc_digest.csrc_digest()) == 64
