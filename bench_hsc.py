@@ -53,12 +53,21 @@ def build_workload(config, B, T, first, level1_taps=17, only_dictionary=False):
 
 
 # ---- roofline of the level >= 1 kernels (sparse input x sparse dictionary, float64) ------------------------------------
-# What bounds them is not bandwidth but the chain of DEPENDENT memory round trips: a round of the blocked selection is a
-# fixed sequence of phases, each waiting for loads whose addresses come out of the previous one, and the signal's state
-# (its dense [T, F] float64 residual, 17-134 MB) lives beyond the L2.  The model below counts those round trips and prices
-# each at the Infinity-Cache hit latency of MI355X_MICROARCH.md (227 ns, idle chip): `frac` = model time / measured time.
-# The HBM side is reported beside it: algorithmic bytes per applied atom against 8 TB/s.
-IC_HIT_LATENCY_S = 227e-9          # MI355X_MICROARCH.md, "global_load_dword (Infinity Cache hit latency)"
+# What bounds them is not bandwidth but the chain of DEPENDENT steps of a round of the blocked selection: memory round trips whose
+# addresses come out of the previous one (the signal's state -- its dense [T, F] float64 residual, 17-134 MB -- lives beyond the L2),
+# and the list work one wave does in LDS between them.  The bound of the round-parallel loop is built from what the in-kernel stamps
+# measured for exactly those two things (profiles/r03_stamps_round_parallel.txt, config 5, workgroup 0):
+#   * a dependent round trip under the loop's own load (eleven waves gathering at once): the window gather of the re-correlation is two
+#     of them, 10 678 cycles per round => 5 339 cycles = 2.2 us each (the idle Infinity-Cache hit of MI355X_MICROARCH.md is 227 ns: the
+#     model of round 3 priced the trips at that and was missed 17 x);
+#   * the serial LDS chain of one wave per round: pairing 5 194 + register sort 5 679 + chains 2 265 + per-row best 3 852 = 16 990 cycles.
+# bound per round = 8 trips x 2.2 us + 7.1 us; everything else a round spends (barrier waits, the candidate phase beside the gather,
+# selection and prefix in wave 0, segment scans) is slack against it: `frac` = bound / measured.  The idle-latency figure stays in the
+# line as `idle_latency_model`.  The HBM side is reported beside it: algorithmic bytes per applied atom against 8 TB/s.
+IC_HIT_LATENCY_S = 227e-9          # MI355X_MICROARCH.md, "global_load_dword (Infinity Cache hit latency)", idle chip
+CLOCK_HZ = 2.4e9
+LOADED_TRIP_S = 5339 / CLOCK_HZ    # one dependent round trip under eleven gathering waves (stamps, see above)
+LDS_CHAIN_S = 16990 / CLOCK_HZ     # pairing + sort + chains + per-row best of one wave, per round (stamps, see above)
 PEAK_HBM_BYTES = 8.0e12
 RP_ROUND_TRIPS = 8                 # round-parallel loop, per ROUND: block arg-max ends | (k, c) + row lists | span cells |
                                    # subtraction: cell + list | list append | window lists | window cells | segment scan
@@ -76,19 +85,25 @@ def level_roofline(Dl, T, B, tm, nbBlocks):
     # write it: 16 B each), the 2W-1 rows of per-position best written back (coefficient 8 B + atom 4 B)
     bytes_per_atom = (W + 3 * W - 2) * 36 + (4 * W - 2) // 2 * 8 + nz * 16 + (2 * W - 1) * 12
     rounds = tm.get('rounds')
-    model_s = None
+    model_s = idle_s = None
+    waves_of_signals = max(1.0, np.ceil(B / 256.0))   # one workgroup per CU: up to 256 signals side by side, the rest queue behind them
     if rp and rounds:
-        # every signal walks its own rounds; one workgroup per CU: up to 256 signals side by side, the rest queue behind them
-        model_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S * max(1.0, np.ceil(B / 256.0))
+        model_s = rounds / B * (RP_ROUND_TRIPS * LOADED_TRIP_S + LDS_CHAIN_S) * waves_of_signals
+        idle_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S * waves_of_signals
     elif not rp:
-        # (co-resident workgroups overlap: two per CU, four in the packed build -- up to 1024 signals walk side by side)
-        model_s = atoms / B * SEQ_ROUND_TRIPS_PER_ATOM * IC_HIT_LATENCY_S * max(1.0, B / 1024.0)
+        # the sequential loops (one team of 256 threads per signal, co-resident workgroups overlap: two per CU, four in the packed
+        # build): no stamped bound yet -- the idle-latency count only, reported as such
+        idle_s = atoms / B * SEQ_ROUND_TRIPS_PER_ATOM * IC_HIT_LATENCY_S * max(1.0, B / 1024.0)
     out = dict(bound='latency', kernel='iterate_rp_kernel<RpSparse>' if rp else 'iterate_kernel<LocompSparse>' if 'locomp' in tm['variant'] else 'iterate_kernel<SparseRecorr>',
                atoms_per_s=atoms / loop_s, us_per_atom_per_signal=1e6 * loop_s * B / atoms,
                dictionary_nonzeros_per_atom=nz,
-               latency_model={'round_trip_s': IC_HIT_LATENCY_S, 'dependent_round_trips': ('%d per round' % RP_ROUND_TRIPS) if rp else ('%d per atom' % SEQ_ROUND_TRIPS_PER_ATOM),
+               latency_model={'loaded_round_trip_s': LOADED_TRIP_S, 'lds_chain_per_round_s': LDS_CHAIN_S,
+                              'dependent_round_trips': ('%d per round' % RP_ROUND_TRIPS) if rp else ('%d per atom' % SEQ_ROUND_TRIPS_PER_ATOM),
                               'rounds_per_signal': (rounds / B) if rounds else None, 'model_ms': None if model_s is None else 1e3 * model_s,
-                              'frac': None if model_s is None else model_s / loop_s},
+                              'frac': None if model_s is None else model_s / loop_s,
+                              'source': 'profiles/r03_stamps_round_parallel.txt (dependent trips under load, serial LDS chain of one wave)'},
+               idle_latency_model={'round_trip_s': IC_HIT_LATENCY_S, 'model_ms': None if idle_s is None else 1e3 * idle_s,
+                                   'frac': None if idle_s is None else idle_s / loop_s},
                hbm={'algorithmic_bytes_per_atom': bytes_per_atom, 'achieved_gb_s': bytes_per_atom * atoms / loop_s / 1e9,
                     'frac': bytes_per_atom * atoms / loop_s / PEAK_HBM_BYTES})
     return out
