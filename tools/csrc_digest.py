@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""sha256 over the engine's sources (csrc/*.hip, csrc/*.h, csrc/Makefile, include/hscmp.h), names and contents in sorted order: the
+"""sha256 over the engine's sources (csrc/*.hip, csrc/*.h, include/hscmp.h, the HIPFLAGS / ARCH lines of csrc/Makefile), names and contents in sorted order: the
 stamp that ties a PMC summary under profiles/ to the kernels it was collected on.  tools/pmc_summary.py writes it into the summary
 (`_csrc_sha256`), bench.py / bench_hsc.py compare it with the tree they run from and report `roofline.traffic = null` +
 `pmc_stale = true` when they differ (a kernel change without a PMC re-run must not keep reporting the old bytes)."""
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def csrc_digest(root=ROOT):
     csrc = os.path.join(root, 'hierarchical-sparse-coding_amd', 'csrc')
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'Makefile')
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h')))
     files.append(os.path.join(root, 'include', 'hscmp.h'))
     h = hashlib.sha256()
     for f in files:
@@ -19,6 +19,12 @@ def csrc_digest(root=ROOT):
         with open(f, 'rb') as fh:
             h.update(fh.read())
         h.update(b'\0')
+    # of the Makefile only what the product library is compiled with (its other targets -- the sanitizer build of the host shim --
+    # do not change the kernels)
+    with open(os.path.join(csrc, 'Makefile')) as fh:
+        for line in fh:
+            if line.startswith(('HIPFLAGS', 'ARCH')):
+                h.update(line.strip().encode() + b'\0')
     return h.hexdigest()
 
 
