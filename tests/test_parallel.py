@@ -180,7 +180,7 @@ def _oracle_hier_encode(xs, mld, **kw):
     return coefs, np.array(energies), events
 
 
-def _hier_worker(rank, world, port, out_dir):
+def _hier_worker(rank, world, port, out_dir, nsig=7):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -190,11 +190,12 @@ def _hier_worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         mld, xs, kw = _hier_inputs()
+        xs = xs[:nsig]
         first, last = shard_bounds(xs.shape[0], world, rank)
         out = encode_sharded_hierarchical(xs[first:last], mld, encode_fn=_oracle_hier_encode, **kw)
         lean = encode_sharded_hierarchical(xs[first:last], mld, encode_fn=_oracle_hier_encode, exact=False, **kw)
         assert lean['bytes_total'] < out['bytes_total']
-        if rank == 1:                               # (every rank holds every signal's results: check the one that is not rank 0)
+        if rank == world - 1:                       # (every rank holds every signal's results: check the last one, not rank 0)
             with open(os.path.join(out_dir, 'hier.pkl'), 'wb') as f:
                 pickle.dump(dict(out=out, lean_coefficients=lean['coefficients']), f)
     finally:
@@ -229,3 +230,24 @@ def test_two_rank_gloo_hierarchical_gather(tmp_path):
     # the payload is per-signal results only: 24 bytes per coefficient (16-byte record + float64 value) + 16 bytes
     nev = max(sum(len(events[b]) for b in range(0, 4)), sum(len(events[b]) for b in range(4, 7)))
     assert 0 < out['bytes_per_signal'] <= 16384 and out['bytes_total'] == 24 * nev + 16 * 4
+
+
+def test_three_rank_gloo_hierarchical_gather_with_an_empty_shard(tmp_path):
+    """Two signals over three ranks: shard sizes 1, 1, 0 -- the rank without a signal still takes part in every collective and ends
+    up with both signals' results."""
+    import pickle
+    import socket
+    import golden_util as gu
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hier_worker, args=(3, port, str(tmp_path), 2), nprocs=3, join=True)
+    with open(os.path.join(str(tmp_path), 'hier.pkl'), 'rb') as f:
+        got = pickle.load(f)['out']
+    mld, xs, kw = _hier_inputs()
+    coefs, energies, events = _oracle_hier_encode(xs[:2], mld, **kw)
+    assert len(got['coefficients']) == 2 and np.array_equal(got['energies'], energies)
+    for b in range(2):
+        assert np.array_equal(got['events'][b], events[b])
+        for l in range(3):
+            assert all(np.array_equal(u, v) for u, v in zip(gu.csc_triplets(got['coefficients'][b][l]), gu.csc_triplets(coefs[b][l])))
