@@ -965,10 +965,16 @@ template <typename R> struct GenericRecorr {
 //   the workgroup.  kGroup = 4 (hscmp_mfma.h): four signals share a 1024-thread workgroup and ONE dictionary
 //   image in LDS; each signal synchronises its own four waves (SoftSync), the signals never wait for each other.
 // ------------------------------------------------------------------------------------------------
-// (hscmp_locomp.h: the atom body of LoCOMP, modeling.py:1314-1383)
+// (hscmp_locomp.h: the atom body of LoCOMP, modeling.py:1314-1383, and what is computed ahead for the selections of a blocked round
+//  that lie far enough apart: lists and fitted coefficients of a group, lane i of the owning wave holding atom i)
+template <typename R> struct LocompPre { int status, n, t, k, si; R a; };      // status 2: ready
+constexpr int kLocompSpacing = 4;      // x W + 4 samples between any two selections of a round that are computed side by side
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy);
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner);
+template <typename R, typename Pol, typename SH, typename SY>
+__device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
+                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy);
 
 template <typename R, typename Recorr>
 __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
@@ -1300,6 +1306,20 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         }
         // =========================== apply the selected atoms (:1101-1142) ===========================
         bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
+        // LoCOMP: are the selections of this round more than 4W + 4 samples apart, every pair of them?  (hscmp_locomp.h)
+        bool lc_spaced = false;
+        int lc_first = 0, lc_count = 0;
+        LocompPre<R> lc_pre{};
+        if constexpr (Recorr::kLocomp) {
+            if (P.blocked && nsel >= 2 && !P.select_only) {
+                int bad = 0;
+                for (int e = tid; e < nsel * nsel; e += kThreads) {
+                    const int i = e / nsel, j = e - i * nsel;
+                    if (i < j && abs(ord_t[i] - ord_t[j]) <= kLocompSpacing * W + 4) bad = 1;
+                }
+                lc_spaced = sy.count(bad) == 0;
+            }
+        }
         for (int ai = 0; ai < nsel; ++ai) {
             int p, k; R c;
             if (!P.blocked) { p = p_sel; k = k_sel; c = c_sel; }
@@ -1314,7 +1334,14 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 continue;
             }
             if constexpr (Recorr::kLocomp) {
-                locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy);
+                // selections far enough apart: neighbourhoods, normal equations and re-fits of up to kWaves of them at once, one
+                // wave each (locomp_precompute), then the applications in order
+                if (lc_spaced && ai == lc_first + lc_count && nsel - ai >= 2) {
+                    lc_first = ai; lc_count = min(kWaves, nsel - ai);
+                    locomp_precompute<R, Recorr>(P, S, G, sh, A, plds, ord_t, ord_k, ord_c, lc_first, lc_count, lc_pre, sy);
+                }
+                const bool ahead = lc_spaced && ai >= lc_first && ai < lc_first + lc_count;
+                locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1);
                 if (sh.skip || sh.converged) break;
                 continue;
             }

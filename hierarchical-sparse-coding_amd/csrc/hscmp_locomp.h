@@ -38,6 +38,7 @@ constexpr double kLocompRankTol = 1e-13;
 
 template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
+    int status, pad_;                 // 2: the lists and fitted coefficients were computed ahead (locomp_precompute)
     int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
     int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
     R a[NMAX];                  // fitted coefficients in the dictionary's dtype (:1329)
@@ -536,7 +537,7 @@ __device__ __forceinline__ void wg_solve(int n, GET get, VGET vget, VSET vset, S
 // uniform guards), lane indices uniform: no LDS traffic, no wave barrier, no dependent memory round trip -- the LDS form took 84 k
 // (10 atoms) to 237 k (18 atoms) cycles per selection at BASELINE config 5, most of it the single-lane substitutions.
 // No pivoting: a pivot below kLocompFastPivot of its atom's own norm (an ill-conditioned or rank-deficient group) returns false and
-// the group goes through the pivoted, rank-revealing path.  g: packed lower triangle, b: right-hand sides, diag: original diagonal.
+// the group goes through the pivoted, rank-revealing path.  g: packed lower triangle (left as it is), b: right-hand sides.
 constexpr double kLocompFastPivot = 1e-6;
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
@@ -545,9 +546,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - dyn_lds()); }
 template <int NF>
-__device__ __attribute__((noinline)) bool locomp_fast_solve(const double* g, const double* b, const double* diag, int n_, double* x_out)
+__device__ __attribute__((noinline)) bool locomp_fast_solve(unsigned g_off, unsigned b_off, int n_, unsigned x_off)
 {
+    // (byte offsets into the workgroup's dynamic LDS, not pointers: a generic pointer to LDS across this call boundary costs flat
+    //  accesses and, with the offsets of locomp_precompute's workspaces, trips the backend -- "Illegal instruction ... src_shared_base")
+    const double* g = reinterpret_cast<const double*>(dyn_lds() + g_off);
+    const double* b = reinterpret_cast<const double*>(dyn_lds() + b_off);
+    double* x_out = reinterpret_cast<double*>(dyn_lds() + x_off);
     const int lane = (int)(threadIdx.x & 63u);
     const int n = __builtin_amdgcn_readfirstlane(n_);
     double row[NF];
@@ -565,7 +572,7 @@ __device__ __attribute__((noinline)) bool locomp_fast_solve(const double* g, con
     for (int j = 0; j < NF; ++j) {
         if (j < n && ok) {                                        // uniform
             const double piv = readlane_f64(row[j], j);
-            if (!(piv > kLocompFastPivot * diag[j])) ok = false;
+            if (!(piv > kLocompFastPivot * g[j * (j + 1) / 2 + j])) ok = false;      // (against the atom's own norm: the original diagonal entry)
             else {
                 const double ljj = sqrt(piv);
                 const double lrj = lane == j ? ljj : row[j] / ljj;
@@ -603,24 +610,180 @@ __device__ __attribute__((noinline)) bool locomp_fast_solve(const double* g, con
     return true;
 }
 
+// ---- the selections of a blocked round side by side, as far as they do not depend on each other -------------------------------
+// The atoms of a blocked round (:908-963) are applied one after the other (:1314), but when they lie more than 4W + 4 samples apart
+// nothing one of them does reaches what another one's neighbourhood, normal equations and re-fit read: neighbours come from positions
+// within 1.5 W of the selected atom, their spans reach 2 W, and a selection changes residual and coefficient slots within 2 W of itself.
+// (BASELINE configs 4 / 5: ten blocks over 65536 samples, 6 500 samples apart.)  So that part -- half of a selection's cycles, most of it
+// one wave's work anyway -- is computed for up to four selections AT ONCE, one wave each, before any of them is applied; the
+// applications (coefficient slots, residual, re-correlation, stop rules) then follow in order, each picking its lists and fitted
+// coefficients up from its wave's registers.  Nothing is written but wave-private LDS, so a round that stops half-way simply drops the rest.
+// The four workspaces alias the memory of the group state the applications go through (Pol::Lds): results leave through registers.
+template <typename R, int NW> struct WaveGroup {
+    int n, pad_;
+    int t[NW], k[NW], si[NW], ut[NW], uk[NW], usi[NW];
+    double b[NW];
+    double g[NW * (NW + 1) / 2];
+    R a[NW];
+};
+template <typename R, typename Pol, typename SH, typename SY>
+__device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
+                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy)
+{
+    constexpr int NW = Pol::kFastGroup >= 32 ? 32 : 16;
+    using WG = WaveGroup<R, NW>;
+    constexpr size_t kStride = (sizeof(typename Pol::Lds) / kWaves) & ~(size_t)15;
+    static_assert(sizeof(WG) <= kStride, "four wave workspaces must fit the group state they alias");
+    typename Pol::Lds& L = Pol::group(P, A, plds);
+    const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
+    pre.status = 0; pre.n = 0; pre.t = 0; pre.k = 0; pre.si = -1; pre.a = (R)0;
+    auto wave_sync = [&]() {                                     // LDS written by a lane of this wave, read by another one
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (wv < count) {
+        WG& w = *reinterpret_cast<WG*>(reinterpret_cast<char*>(&L) + (size_t)wv * kStride);
+        const int p = ord_t[first + wv], k = ord_k[first + wv];
+        const R c = ord_c[first + wv];
+        int s0, e0, es0;
+        centered_span(T, W, p, s0, e0, es0);
+        const int nstart = max(s0 - W / 2, 0);
+        const int nend = min((e0 - 1) + ((W & 1) ? W / 2 : W / 2 - 1), T);
+        const int nlast = min(nend, T - 1);
+        if (lane == 0) { w.n = 0; w.t[0] = p; w.k[0] = k; w.si[0] = -1; }
+        wave_sync();
+        for (int ti = nstart + lane; ti <= nlast; ti += 64)          // :1222-1241 through the per-position slot chains
+            for (int i = hval_load(G.head + ti); i >= 0; i = hval_load(G.hval + i)) {
+                const int ki = G.slot_k[i];
+                if (ti == p && ki == k) w.si[0] = i;
+                if (ki == k || (ti - nstart) == p) continue;
+                if (!(G.slot_a[i] != 0.0)) continue;
+                const int o = atomicAdd(&w.n, 1);
+                if (o < NW - 1) { w.ut[o] = ti; w.uk[o] = ki; w.usi[o] = i; }
+            }
+        wave_sync();
+        const int m = __builtin_amdgcn_readfirstlane(w.n);
+        bool ok = m <= NW - 1;                                       // (a larger group: the selection goes the usual way)
+        if (ok) {
+            if (lane < m) {                                          // group order: (position, atom) ascending behind the selected atom
+                const long long key = ((long long)w.ut[lane] << 32) | (unsigned)w.uk[lane];
+                int rank = 0;
+                for (int q = 0; q < m; ++q) rank += ((((long long)w.ut[q] << 32) | (unsigned)w.uk[q]) < key) ? 1 : 0;
+                w.t[1 + rank] = w.ut[lane]; w.k[1 + rank] = w.uk[lane]; w.si[1 + rank] = w.usi[lane];
+            }
+            wave_sync();
+            const int n = 1 + m;
+            if (n > 1) {
+                const int nitems = n + n * (n + 1) / 2;
+                const int* nzp = nullptr; const int* nzwf = nullptr; const R* nzv = nullptr;
+                if (Pol::atom_lists(P, A, plds, nzp, nzwf, nzv)) {       // uniform: sparse dictionary, one lane per item
+                    for (int it = lane; it < nitems; it += 64) {
+                        double acc = 0.0;
+                        if (it < n) {
+                            const int ti = w.t[it] - P.off, ki = w.k[it];
+                            for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
+                                const int wf = nzwf[e], row = ti + (wf >> 16);
+                                if (row >= 0 && row < T) acc += (double)nzv[e] * (double)G.r[(int64_t)row * F + (wf & 0xffff)];
+                            }
+                            w.b[it] = acc;
+                        } else {
+                            int i, j;
+                            tri_decode(it - n, i, j);
+                            const int ti = w.t[i] - P.off, tj = w.t[j] - P.off, ki = w.k[i], kj = w.k[j];
+                            const int ej0 = nzp[kj], ej1 = nzp[kj + 1];
+                            for (int e = nzp[ki]; e < nzp[ki + 1]; ++e) {
+                                const int wf = nzwf[e], row = ti + (wf >> 16);
+                                if (row < 0 || row >= T) continue;
+                                const int want = ((row - tj) << 16) | (wf & 0xffff);
+                                if (row - tj < 0 || row - tj >= W) continue;
+                                for (int e2 = ej0; e2 < ej1; ++e2)
+                                    if (nzwf[e2] == want) acc += (double)nzv[e] * (double)nzv[e2];
+                            }
+                            w.g[i * (i + 1) / 2 + j] = acc;
+                        }
+                    }
+                } else {                                                 // dense dictionary: eight lanes per item
+                    for (int it = lane >> 3; it < nitems; it += 8) {
+                        const int sub = lane & 7;
+                        double acc = 0.0;
+                        int i = 0, j = 0;
+                        if (it < n) {
+                            int s_, e_, es_;
+                            const int len = centered_span(T, W, w.t[it], s_, e_, es_);
+                            const R* dk = S.D + ((int64_t)w.k[it] * W + es_) * F;
+                            const R* rv = G.r + (int64_t)s_ * F;
+                            for (int x = sub; x < len * F; x += 8) acc += (double)dk[x] * (double)rv[x];
+                        } else {
+                            tri_decode(it - n, i, j);
+                            int si_, ei_, esi, sj_, ej_, esj;
+                            centered_span(T, W, w.t[i], si_, ei_, esi);
+                            centered_span(T, W, w.t[j], sj_, ej_, esj);
+                            const int lo = max(si_, sj_), hi = min(ei_, ej_);
+                            if (hi > lo) {
+                                const R* di = S.D + ((int64_t)w.k[i] * W + (lo - si_ + esi)) * F;
+                                const R* dj = S.D + ((int64_t)w.k[j] * W + (lo - sj_ + esj)) * F;
+                                for (int x = sub; x < (hi - lo) * F; x += 8) acc += (double)di[x] * (double)dj[x];
+                            }
+                        }
+                        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+                        if (sub == 0) { if (it < n) w.b[it] = acc; else w.g[i * (i + 1) / 2 + j] = acc; }
+                    }
+                }
+                wave_sync();
+                if (n <= 8) ok = locomp_fast_solve<8>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
+                else if (n <= 16) ok = locomp_fast_solve<16>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
+                else ok = locomp_fast_solve<NW>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                wave_sync();
+            }
+            if (ok) {
+                pre.status = 2; pre.n = n;
+                if (lane < n) { pre.t = w.t[lane]; pre.k = w.k[lane]; pre.si = w.si[lane]; pre.a = n > 1 ? (R)w.b[lane] : c; }
+            }
+        }
+    }
+    sy.full();
+}
+
 // One selected atom (p, k, c): modeling.py:1314-1383.  All threads of the signal's workgroup; the caller leaves the atom
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy)
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner)
 {
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
     typename Pol::Lds& L = Pol::group(P, A, plds);
     constexpr int kCap = Pol::kMaxGroup;
     const GroupGlobal GG = group_global(G.lgram, P.lg_cap);
     HSCMP_STAMP_BEGIN();
-    // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
-    if (tid == 0) {
-        if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
-        L.cnt = 0; L.t[0] = p; L.k[0] = k; L.si[0] = -1; L.loss = (R)0; L.last_e = sh.e_res;
+    // lists and fitted coefficients computed ahead (locomp_precompute; owner: the wave whose registers hold them)?
+    bool have = false;
+    if (owner >= 0) {                                            // uniform
+        if (wv == owner) {
+            const int st = pre.status;
+            if (st == 2) {
+                if (lane < pre.n) { L.t[lane] = pre.t; L.k[lane] = pre.k; L.si[lane] = pre.si; L.a[lane] = pre.a; }
+                if (lane == 0) {
+                    L.n = pre.n; L.cnt = pre.n - 1; L.loss = (R)0; L.last_e = sh.e_res;
+                    if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
+                }
+            }
+            if (lane == 0) L.status = st;
+        }
+        sy.full();
+        if (sh.skip) return;
+        have = L.status == 2;
     }
-    sy.full();
-    if (sh.skip) return;
+    // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
+    if (!have) {
+        if (tid == 0) {
+            if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
+            L.cnt = 0; L.t[0] = p; L.k[0] = k; L.si[0] = -1; L.loss = (R)0; L.last_e = sh.e_res;
+        }
+        sy.full();
+        if (sh.skip) return;
+    }
     int s0, e0, es0;
     centered_span(T, W, p, s0, e0, es0);
     const int nstart = max(s0 - W / 2, 0);
@@ -629,16 +792,18 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     // prologue builds the chains, the bookkeeping below extends them): the neighbourhood is a walk over the chains of its 2W + 1
     // positions, one thread each, instead of a scan of the whole slot list (14 k slots per signal at BASELINE config 5)
     const int nlast = min(nend, T - 1);
-    for (int ti = nstart + tid; ti <= nlast; ti += kThreads)
-        for (int i = hval_load(G.head + ti); i >= 0; i = hval_load(G.hval + i)) {
-            const int ki = G.slot_k[i];
-            if (ti == p && ki == k) L.si[0] = i;                 // (at most one)
-            if (ki == k || (ti - nstart) == p) continue;
-            if (!(G.slot_a[i] != 0.0)) continue;                  // (the list-of-lists matrix drops an entry that became 0.0)
-            const int o = atomicAdd(&L.cnt, 1);
-            if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
-        }
-    sy.full();
+    if (!have) {
+        for (int ti = nstart + tid; ti <= nlast; ti += kThreads)
+            for (int i = hval_load(G.head + ti); i >= 0; i = hval_load(G.hval + i)) {
+                const int ki = G.slot_k[i];
+                if (ti == p && ki == k) L.si[0] = i;                 // (at most one)
+                if (ki == k || (ti - nstart) == p) continue;
+                if (!(G.slot_a[i] != 0.0)) continue;                  // (the list-of-lists matrix drops an entry that became 0.0)
+                const int o = atomicAdd(&L.cnt, 1);
+                if (o < kCap - 1) { L.ut[o] = ti; L.uk[o] = ki; L.usi[o] = i; }
+            }
+        sy.full();
+    }
     HSCMP_STAMP(0);                                              // neighbourhood scan
     const int m = L.cnt;
     if (m > P.lg_cap - 1) {                                      // uniform: beyond the signal's scratch too (hscmp_params / HSCMP_LOCOMP_GROUP_CAP)
@@ -674,6 +839,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     auto UT_ = [&](int i) -> int { return bigL ? gld(GG.ut + i) : L.ut[i]; };
     auto setUT = [&](int i, int v) { if (bigL) gst(GG.ut + i, v); else L.ut[i] = v; };
     // group order: the new atom, then the neighbours by (position, atom) -- the order of the reference's sparse slice
+    if (!have)
     for (int i = tid; i < m; i += kThreads) {
         const int ui = UT_(i), uki = bigL ? gld(GG.uk + i) : L.uk[i], usi = bigL ? gld(GG.usi + i) : L.usi[i];
         const long long key = ((long long)ui << 32) | (unsigned)uki;
@@ -685,12 +851,14 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         if (bigL) { gst(GG.t + 1 + rank, ui); gst(GG.k + 1 + rank, uki); gst(GG.si + 1 + rank, usi); }
         else { L.t[1 + rank] = ui; L.k[1 + rank] = uki; L.si[1 + rank] = usi; }
     }
-    if (tid == 0) {
-        L.n = 1 + m;
-        if (bigL) { gst(GG.t, p); gst(GG.k, k); gst(GG.si, L.si[0]); gst(GG.a, (double)c); }
-        else L.a[0] = c;
+    if (!have) {
+        if (tid == 0) {
+            L.n = 1 + m;
+            if (bigL) { gst(GG.t, p); gst(GG.k, k); gst(GG.si, L.si[0]); gst(GG.a, (double)c); }
+            else L.a[0] = c;
+        }
+        sy.full();
     }
-    sy.full();
     const int n = 1 + m;
     HSCMP_STAMP(1);                                              // group order
 #ifdef HSCMP_DBG_STAMPS
@@ -702,7 +870,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     double* gglob = GG.gram;
     auto gl = [&](int idx) -> double { return big ? gld(gglob + idx) : L.g[idx]; };
     auto gs = [&](int idx, double v) { if (big) gst(gglob + idx, v); else L.g[idx] = v; };
-    if (n > 1) {
+    if (n > 1 && !have) {
         // ---- :1322-1329 least squares of the local residual on the group's (clipped) atoms: G x = b, float64
         // items: n right-hand sides, then the n (n + 1) / 2 Gram entries; one wave per item, lanes over the elements
         const int nitems = n + n * (n + 1) / 2;
@@ -817,10 +985,10 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             if (wv == 0) {
                 // (three unrollings: the guards of the unused steps are what a small group would pay for)
                 bool ok;
-                if (n <= 8) ok = locomp_fast_solve<8>(L.g, L.b, L.diag, n, L.b);
-                else if (kFast >= 16 && n <= 16) ok = locomp_fast_solve<16>(L.g, L.b, L.diag, n, L.b);
-                else if (kFast > 32 && n <= 32) ok = locomp_fast_solve<32>(L.g, L.b, L.diag, n, L.b);
-                else ok = locomp_fast_solve<kFast>(L.g, L.b, L.diag, n, L.b);
+                if (n <= 8) ok = locomp_fast_solve<8>(lds_off(L.g), lds_off(L.b), n, lds_off(L.b));
+                else if (kFast >= 16 && n <= 16) ok = locomp_fast_solve<16>(lds_off(L.g), lds_off(L.b), n, lds_off(L.b));
+                else if (kFast > 32 && n <= 32) ok = locomp_fast_solve<32>(lds_off(L.g), lds_off(L.b), n, lds_off(L.b));
+                else ok = locomp_fast_solve<kFast>(lds_off(L.g), lds_off(L.b), n, lds_off(L.b));
                 if (lane == 0) L.cnt = ok ? n : -1;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
