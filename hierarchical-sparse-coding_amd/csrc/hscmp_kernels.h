@@ -967,11 +967,14 @@ template <typename R> struct GenericRecorr {
 // ------------------------------------------------------------------------------------------------
 // (hscmp_locomp.h: the atom body of LoCOMP, modeling.py:1314-1383, and what is computed ahead for the selections of a blocked round
 //  that lie far enough apart: lists and fitted coefficients of a group, lane i of the owning wave holding atom i)
-template <typename R> struct LocompPre { int status, n, t, k, si; R a; };      // status 2: ready
+template <typename R> struct LocompPre {
+    int status, n, t, k, si; R a;       // status 2: lists + fitted coefficients ready; 3: also applied on a private copy of the residual:
+    int u0, ulen; R loss; R span[4];    //   samples [u0, u0 + ulen) (lane l holds l, l + 64, ...) and the group's energy loss
+};
 constexpr int kLocompSpacing = 4;      // x W + 4 samples between any two selections of a round that are computed side by side
 template <typename R, typename Pol, typename SH, typename SY>
-__device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner);
+__device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner);      // true: taken from `pre`
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
                                                   const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy);
@@ -1341,7 +1344,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                     locomp_precompute<R, Recorr>(P, S, G, sh, A, plds, ord_t, ord_k, ord_c, lc_first, lc_count, lc_pre, sy);
                 }
                 const bool ahead = lc_spaced && ai >= lc_first && ai < lc_first + lc_count;
-                locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1);
+                (void)locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1);
                 if (sh.skip || sh.converged) break;
                 continue;
             }

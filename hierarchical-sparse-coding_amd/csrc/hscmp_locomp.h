@@ -636,7 +636,8 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
     static_assert(sizeof(WG) <= kStride, "four wave workspaces must fit the group state they alias");
     typename Pol::Lds& L = Pol::group(P, A, plds);
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
-    pre.status = 0; pre.n = 0; pre.t = 0; pre.k = 0; pre.si = -1; pre.a = (R)0;
+    pre.status = 0; pre.n = 0; pre.t = 0; pre.k = 0; pre.si = -1; pre.a = (R)0; pre.u0 = 0; pre.ulen = 0; pre.loss = (R)0;
+    pre.span[0] = pre.span[1] = pre.span[2] = pre.span[3] = (R)0;
     auto wave_sync = [&]() {                                     // LDS written by a lane of this wave, read by another one
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -741,6 +742,71 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                 pre.status = 2; pre.n = n;
                 if (lane < n) { pre.t = w.t[lane]; pre.k = w.k[lane]; pre.si = w.si[lane]; pre.a = n > 1 ? (R)w.b[lane] : c; }
             }
+            // Dense dictionary, short atoms: the group's subtractions too, on a PRIVATE copy of the stretch of the residual they touch
+            // (in the LDS the normal equations have left; at most 256 samples, which then travel in four registers per lane) -- atom
+            // after atom with the local energies of :996-1016, the same products, sums and trees as apply on the residual itself.
+            if constexpr (Pol::kWaveApply) {
+                if (ok && W * F <= 1024) {
+                    int s_lo = T, e_hi = 0;
+                    if (lane < n) { int s_, e_, es_; centered_span(T, W, w.t[lane], s_, e_, es_); s_lo = s_; e_hi = e_; }
+#pragma unroll
+                    for (int m_ = 32; m_ >= 1; m_ >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, m_)); e_hi = max(e_hi, __shfl_xor(e_hi, m_)); }
+                    const int u0 = s_lo, ulen = (e_hi - s_lo) * F;
+                    if (ulen <= 256 && (size_t)ulen * sizeof(R) <= sizeof(w.g)) {
+                        R* cp = reinterpret_cast<R*>(w.g);
+                        const R* src = G.r + (int64_t)u0 * F;
+                        for (int i = lane; i < ulen; i += 64) cp[i] = src[i];
+                        wave_sync();
+                        R loss = (R)0;
+                        for (int gi = 0; gi < n; ++gi) {
+                            const int tp = w.t[gi], kk = w.k[gi];
+                            const R cf = n > 1 ? (R)w.b[gi] : c;
+                            int s, e, es;
+                            const int cnt = centered_span(T, W, tp, s, e, es) * F;
+                            const R nc = -cf;
+                            const R* dk = S.D + ((int64_t)kk * W + es) * F;
+                            R* rv = cp + (s - u0) * F;
+                            R b4[4] = {(R)0, (R)0, (R)0, (R)0}, a4[4] = {(R)0, (R)0, (R)0, (R)0};
+                            for (int i0 = lane; i0 < cnt; i0 += kThreads) {
+                                R v[4], d[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = (R)0; d[u] = (R)0; if (i < cnt) { v[u] = rv[i]; d[u] = dk[i]; } }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int i = i0 + 64 * u;
+                                    if (i < cnt) {
+                                        const R sq = v[u] * v[u];
+                                        b4[u] = b4[u] + sq;
+                                        const R prod = nc * d[u];            // -c*D[k] rounded, then += (utils.py:120,129)
+                                        const R vn = v[u] + prod;
+                                        rv[i] = vn;
+                                        const R sq2 = vn * vn;
+                                        a4[u] = a4[u] + sq2;
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int m_ = 32; m_ >= 1; m_ >>= 1) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const R ob = __shfl_down(b4[u], m_), oa = __shfl_down(a4[u], m_);
+                                    b4[u] = b4[u] + ob; a4[u] = a4[u] + oa;
+                                }
+                            }
+                            {
+                                const R b01 = b4[0] + b4[1], b23 = b4[2] + b4[3], a01 = a4[0] + a4[1], a23 = a4[2] + a4[3];
+                                const R pb = b01 + b23, pa = a01 + a23;
+                                const R l = pb - pa;
+                                loss = loss + l;                         // (lane 0 holds the group's sum, :1005)
+                            }
+                            wave_sync();
+                        }
+                        pre.status = 3; pre.u0 = u0; pre.ulen = ulen; pre.loss = __shfl(loss, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; pre.span[u] = i < ulen ? cp[i] : (R)0; }
+                    }
+                }
+            }
         }
     }
     sy.full();
@@ -749,7 +815,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
 // One selected atom (p, k, c): modeling.py:1314-1383.  All threads of the signal's workgroup; the caller leaves the atom
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
-__device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
+__device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
                                             char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner)
 {
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
@@ -758,22 +824,30 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     const GroupGlobal GG = group_global(G.lgram, P.lg_cap);
     HSCMP_STAMP_BEGIN();
     // lists and fitted coefficients computed ahead (locomp_precompute; owner: the wave whose registers hold them)?
-    bool have = false;
+    bool have = false, applied_ahead = false;
     if (owner >= 0) {                                            // uniform
         if (wv == owner) {
             const int st = pre.status;
-            if (st == 2) {
+            if (st >= 2) {
                 if (lane < pre.n) { L.t[lane] = pre.t; L.k[lane] = pre.k; L.si[lane] = pre.si; L.a[lane] = pre.a; }
+                bool full = false;
                 if (lane == 0) {
-                    L.n = pre.n; L.cnt = pre.n - 1; L.loss = (R)0; L.last_e = sh.e_res;
-                    if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
+                    L.n = pre.n; L.cnt = pre.n - 1; L.loss = st == 3 ? pre.loss : (R)0; L.last_e = sh.e_res;
+                    if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; full = true; }
+                }
+                full = __shfl(full ? 1 : 0, 0) != 0;
+                if (st == 3 && !full) {                          // the residual of the group's span, as its atoms left it on the private copy
+                    R* dst = G.r + (int64_t)pre.u0 * F;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; if (i < pre.ulen) dst[i] = pre.span[u]; }
                 }
             }
             if (lane == 0) L.status = st;
         }
         sy.full();
-        if (sh.skip) return;
-        have = L.status == 2;
+        if (sh.skip) return false;
+        have = L.status >= 2;
+        applied_ahead = L.status == 3;
     }
     // ---- event list, the atom's own entry, its neighbourhood (:1222-1241)
     if (!have) {
@@ -782,7 +856,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
             L.cnt = 0; L.t[0] = p; L.k[0] = k; L.si[0] = -1; L.loss = (R)0; L.last_e = sh.e_res;
         }
         sy.full();
-        if (sh.skip) return;
+        if (sh.skip) return false;
     }
     int s0, e0, es0;
     centered_span(T, W, p, s0, e0, es0);
@@ -809,7 +883,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     if (m > P.lg_cap - 1) {                                      // uniform: beyond the signal's scratch too (hscmp_params / HSCMP_LOCOMP_GROUP_CAP)
         if (tid == 0) { sh.converged = 1; sh.stop = STOP_GROUP; sh.skip = 1; }
         sy.full();
-        return;
+        return false;
     }
     // more neighbours than the LDS lists hold: the lists of this group live in the signal's global scratch
     const bool bigL = m > kCap - 1;                              // uniform
@@ -1158,7 +1232,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     }
     // A policy that knows the cells of its atoms (sparse dictionary, row lists) applies the whole group in one pass
     bool grouped = false;
-    if constexpr (Pol::kGroupUpdate) {
+    if constexpr (Pol::kGroupUpdate) if (!applied_ahead) {
         R gloss = (R)0;
         grouped = Pol::group_update(P, G, A, plds, n, T_, K_, A_, gloss, sh.red, sy);        // uniform
         if (grouped && tid == 0) L.loss = L.loss + gloss;
@@ -1167,7 +1241,8 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
     // atom.  Lane l carries the four strided partial sums l, 64+l, 128+l, 192+l of the workgroup form (wave_window_energy):
     // the same trees, the same bits.
     const bool wave_apply = Pol::kWaveApply && W * F <= 1024;            // uniform
-    if (grouped) sy.full();
+    if (applied_ahead) sy.full();                                        // (the owning wave has stored the span; its loss is in L.loss)
+    else if (grouped) sy.full();
     else if (wave_apply) {
         if (wv == 0)
             for (int gi = 0; gi < n; ++gi) {
@@ -1290,7 +1365,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         const int lo = max(0, tp - (W - 1)), hi = min(T - 1, tp + (W - 1));
         const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
         if (P.blocked) {
-            if (tid == 0) for (int sg = sg0; sg <= sg1; ++sg) sh.touched[sg >> 5] |= 1u << (sg & 31);
+            if (tid == (gi & (kThreads - 1))) for (int sg = sg0; sg <= sg1; ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
         } else {
             for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<false>(P, G, wts, sh, sg, lane);
         }
@@ -1315,6 +1390,7 @@ __device__ __forceinline__ void locomp_atom(const DevParams& P, const State<R>& 
         }
     }
     sy.full();
+    return have;
 }
 
 }  // namespace hscmp
