@@ -197,6 +197,7 @@ struct DevParams {
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
     int lg_cap;         // LoCOMP: atoms of the largest group the signal's global scratch holds (lgram_doubles; larger: STOP_GROUP)
+    int lc_ahead;       // LoCOMP: 1 = the selections of a round that lie far enough apart are computed side by side (hscmp_locomp.h)
 };
 
 // LoCOMP: doubles of global scratch per signal for a group of up to `cap` atoms (hscmp_locomp.h, GroupGlobal): two packed triangles

@@ -434,3 +434,32 @@ def test_table_calls_without_open_table_fail_loudly():
     with pytest.raises(_native.HscmpError):
         tab.read()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', range(len(BATCH_CASES)))
+def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case, monkeypatch):
+    """Blocked rounds whose selections lie more than 4W + 4 samples apart get neighbourhood, normal equations, re-fit (and, with a dense
+    dictionary, the subtractions on a private copy of the span) of up to four selections computed at once, one wave each, before they
+    are applied in order (locomp_precompute).  HSCMP_LOCOMP_AHEAD=0 applies the same rounds selection by selection: every signal of
+    every policy bit for bit -- long signals with few blocks so that the rounds really are spaced."""
+    from hsc_amd.modeling import LoCOMP
+    T, K, W, F, dtype, natoms, kw, sp = BATCH_CASES[case]
+    T = 40 * W * 6
+    x, D = _planted(T, K, W, F, dtype, 300 + case, 12 * natoms, sp)
+    kw = dict(kw)
+    kw['nbBlocks'] = 6
+    if kw.get('weights') == 'w':
+        kw['weights'] = np.linspace(0.6, 1.0, K).astype(dtype)
+    if 'nbNonzeroCoefs' in kw:
+        kw['nbNonzeroCoefs'] = 8 * kw['nbNonzeroCoefs']
+    rs = np.random.RandomState(case)
+    xs = np.stack([x, (0.5 * x).astype(dtype), x[::-1].copy(), (x + 0.02 * rs.standard_normal(x.shape)).astype(dtype)])
+    ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+    monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '0')
+    seq = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+    assert np.array_equal(ahead.stats, seq.stats) and np.array_equal(ahead.energies, seq.energies)
+    assert int(ahead.stats[:, 4].sum()) > 4 * xs.shape[0]          # (several selections per signal)
+    for b in range(xs.shape[0]):
+        assert (ahead.coefficients[b] != seq.coefficients[b]).nnz == 0 and np.array_equal(ahead.residuals[b], seq.residuals[b]), b
+        assert all(np.array_equal(u, v) for u, v in zip(ahead.events[b], seq.events[b])), b
