@@ -432,7 +432,7 @@ def run_secondary(args, ctx):
     # (config 4 also with the method the reference's own script runs it with -- learn_mlcsc_dataset.py:108 builds the encoder with
     #  its default, LoCOMP: the device loop of csrc/hscmp_locomp.h)
     for name, config, taps, method in (('config4_17taps', 4, 17, 'cmp'), ('config4_16taps', 4, 16, 'cmp'), ('config5', 5, 17, 'cmp'),
-                                       ('config4_17taps_locomp', 4, 17, 'locomp')):
+                                       ('config4_17taps_locomp', 4, 17, 'locomp'), ('config5_locomp', 5, 17, 'locomp')):
         if time.perf_counter() - t_begin > args.secondary_budget_s:
             sec[name] = {'skipped': 'time budget of the secondary section (%d s) spent' % args.secondary_budget_s}
             continue
