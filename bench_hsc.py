@@ -61,13 +61,15 @@ def build_workload(config, B, T, first, level1_taps=17, only_dictionary=False):
 #     of them, 10 678 cycles per round => 5 339 cycles = 2.2 us each (the idle Infinity-Cache hit of MI355X_MICROARCH.md is 227 ns: the
 #     model of round 3 priced the trips at that and was missed 17 x);
 #   * the serial LDS chain of one wave per round: pairing 5 194 + register sort 5 679 + chains 2 265 + per-row best 3 852 = 16 990 cycles.
-# bound per round = 8 trips x 2.2 us + 7.1 us; everything else a round spends (barrier waits, the candidate phase beside the gather,
+# model per round = 8 trips x 2.2 us + 7.1 us x (3W - 2) / 145 (the chain scaled to the level's window); everything else a round spends (barrier waits, the candidate phase beside the gather,
 # selection and prefix in wave 0, segment scans) is slack against it: `frac` = bound / measured.  The idle-latency figure stays in the
 # line as `idle_latency_model`.  The HBM side is reported beside it: algorithmic bytes per applied atom against 8 TB/s.
 IC_HIT_LATENCY_S = 227e-9          # MI355X_MICROARCH.md, "global_load_dword (Infinity Cache hit latency)", idle chip
 CLOCK_HZ = 2.4e9
 LOADED_TRIP_S = 5339 / CLOCK_HZ    # one dependent round trip under eleven gathering waves (stamps, see above)
 LDS_CHAIN_S = 16990 / CLOCK_HZ     # pairing + sort + chains + per-row best of one wave, per round (stamps, see above)
+LDS_CHAIN_ROWS = 3 * 49 - 2        # ... measured on windows of 3W - 2 rows with W = 33 and 65 (config 5 levels 1 / 2, both in the stamps):
+                                   # the lists that chain walks grow with the rows of a window, so it is scaled by (3W - 2) / 145
 PEAK_HBM_BYTES = 8.0e12
 RP_ROUND_TRIPS = 8                 # round-parallel loop, per ROUND: block arg-max ends | (k, c) + row lists | span cells |
                                    # subtraction: cell + list | list append | window lists | window cells | segment scan
@@ -88,7 +90,7 @@ def level_roofline(Dl, T, B, tm, nbBlocks):
     model_s = idle_s = None
     waves_of_signals = max(1.0, np.ceil(B / 256.0))   # one workgroup per CU: up to 256 signals side by side, the rest queue behind them
     if rp and rounds:
-        model_s = rounds / B * (RP_ROUND_TRIPS * LOADED_TRIP_S + LDS_CHAIN_S) * waves_of_signals
+        model_s = rounds / B * (RP_ROUND_TRIPS * LOADED_TRIP_S + LDS_CHAIN_S * (3 * W - 2) / LDS_CHAIN_ROWS) * waves_of_signals
         idle_s = rounds / B * RP_ROUND_TRIPS * IC_HIT_LATENCY_S * waves_of_signals
     elif not rp:
         # the sequential loops (one team of 256 threads per signal, co-resident workgroups overlap: two per CU, four in the packed
@@ -97,7 +99,7 @@ def level_roofline(Dl, T, B, tm, nbBlocks):
     out = dict(bound='latency', kernel='iterate_rp_kernel<RpSparse>' if rp else 'iterate_kernel<LocompSparse>' if 'locomp' in tm['variant'] else 'iterate_kernel<SparseRecorr>',
                atoms_per_s=atoms / loop_s, us_per_atom_per_signal=1e6 * loop_s * B / atoms,
                dictionary_nonzeros_per_atom=nz,
-               latency_model={'loaded_round_trip_s': LOADED_TRIP_S, 'lds_chain_per_round_s': LDS_CHAIN_S,
+               latency_model={'loaded_round_trip_s': LOADED_TRIP_S, 'lds_chain_per_round_s': LDS_CHAIN_S * (3 * W - 2) / LDS_CHAIN_ROWS,
                               'dependent_round_trips': ('%d per round' % RP_ROUND_TRIPS) if rp else ('%d per atom' % SEQ_ROUND_TRIPS_PER_ATOM),
                               'rounds_per_signal': (rounds / B) if rounds else None, 'model_ms': None if model_s is None else 1e3 * model_s,
                               'frac': None if model_s is None else model_s / loop_s,
