@@ -7,16 +7,20 @@
 //               -- minus those that share its dictionary index, minus those whose row INSIDE THAT WINDOW equals the atom's
 //               absolute position (the reference compares the two as they are; reproduced) -- form its group;
 //   :1322-1341  the coefficients of the group are re-fitted on the local residual: least squares over the union of the
-//               supports (np.linalg.pinv there; here the normal equations of the same system in float64, Cholesky -- the
-//               Gram matrix of a handful of atoms), ADDED to the stored coefficients, and every atom of the group is
-//               removed from the residual and re-correlated around (:1343-1353);
+//               supports (np.linalg.pinv there; here the normal equations of the same system in float64 -- in registers for a
+//               usual group, locomp_fast_solve; a diagonally pivoted, rank-revealing factorisation with the minimum-norm
+//               completion, which is pinv's answer, for a rank-deficient or ill-conditioned one), ADDED to the stored
+//               coefficients, and every atom of the group is removed from the residual and re-correlated around (:1343-1353);
 //   :1368-1383  `coefficients.nnz` (stored non-zeros: an entry that cancels to 0.0 leaves the count) is what nbNonzeroCoefs
 //               is compared with, and the loop also stops when an atom changes the residual energy by less than eps.
 // Selection, weak-atom filter, residual subtraction with its local energies, local re-correlation and the round-level stop
 // rules are those of the greedy loop and run through the same code.  Three policies: LocompRecorr (the table-free dense form, any
 // shape), LocompSparse (multi-feature inputs with a sparse dictionary: hierarchical levels >= 1), LocompMfma (single-feature float32:
 // re-correlations and the initial correlation on the matrix cores, up to four signals per workgroup around one dictionary image).
-// Parity is at tolerance level by construction (the reference's pseudo-inverse is an SVD in the dictionary's dtype).
+// The selections of a blocked round that lie far enough apart get all of that up to the fitted coefficients computed side by side,
+// one wave each (locomp_precompute), before they are applied in order.
+// Parity is at tolerance level by construction (the reference's pseudo-inverse is an SVD in the dictionary's dtype); the supports are
+// exact on the reference's goldens (tests/test_locomp_hier.py: per-fixture tolerances from the conditioning its pseudo-inverse saw).
 #pragma once
 #include "hscmp_kernels.h"
 #include "hscmp_mfma.h"
@@ -577,9 +581,11 @@ __device__ __attribute__((noinline)) bool locomp_fast_solve(unsigned g_off, unsi
                 const double ljj = sqrt(piv);
                 const double lrj = lane == j ? ljj : row[j] / ljj;
                 if (lane >= j) row[j] = lrj;
+                // (NF > 32: no guard per column -- thousands of tiny basic blocks are what the compiler chokes on; a column beyond n
+                //  is all zeros in every lane that would take the update, except entry n of the b row, which nobody reads)
 #pragma unroll
                 for (int q = j + 1; q < NF; ++q)
-                    if (q < n) {
+                    if (NF > 32 || q < n) {
                         const double lqj = readlane_f64(row[j], q);
                         if (lane >= q) row[q] -= lrj * lqj;
                     }

@@ -55,8 +55,9 @@ typedef enum hscmp_stop {
     HSCMP_STOP_CALLBACK = 6,       /* modeling.py:1155-1158, decided by the host between rounds */
     HSCMP_STOP_CAPACITY = 7,       /* event buffer full: re-run with a larger max_events */
     HSCMP_STOP_STALLED = 8,        /* LoCOMP only, modeling.py:1379-1383: an atom changed the residual energy by less than eps */
-    HSCMP_STOP_GROUP = 9           /* LoCOMP only: a neighbourhood of more than 127 atoms (modeling.py:1222-1241); nothing of the
-                                      atom was applied -- the caller repeats such a signal through the table entry points */
+    HSCMP_STOP_GROUP = 9           /* LoCOMP only: a neighbourhood beyond the signal's group scratch (more than 511 atoms around one
+                                      selection; HSCMP_LOCOMP_GROUP_CAP lowers it), modeling.py:1222-1241; nothing of that atom has been
+                                      applied: repeat the signal through the hscmp_table_* loop (or the reference's own LoCOMP) */
 } hscmp_stop;
 
 /* which loop hscmp_encode_batch* / hscmp_continue run: ConvolutionalMatchingPursuit.computeCoefficients (modeling.py:1053-1186)
