@@ -463,3 +463,29 @@ def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case,
     for b in range(xs.shape[0]):
         assert (ahead.coefficients[b] != seq.coefficients[b]).nnz == 0 and np.array_equal(ahead.residuals[b], seq.residuals[b]), b
         assert all(np.array_equal(u, v) for u, v in zip(ahead.events[b], seq.events[b])), b
+
+
+@pytest.mark.gpu
+def test_locomp_large_groups_down_to_round_off():
+    """30 samples x 12 features under 48 atoms of 5 taps, pursued far down: groups of more than 135 atoms (lists, Gram matrix and the
+    pivoted factorisation in the signal's global scratch, all threads of the workgroup) that come close to the number of cells they
+    span.  At 100 dB (residual 3e-8) device loop and host loop (np.linalg.pinv in float64) agree to 1e-12; at 150 dB the pursuit is in
+    round-off (residual 1e-13, the last atoms have coefficients of 1e-7): same atoms of size, coefficients to 1e-5."""
+    from hsc_amd.modeling import LoCOMP
+    rs = np.random.RandomState(8)
+    K, W, T, F = 48, 5, 30, 12
+    D = rs.standard_normal((K, W, F)).astype(np.float64)
+    D /= np.sqrt(np.sum(D ** 2, axis=(1, 2), keepdims=True))
+    x = rs.standard_normal((T, F))
+    for snr, tol, floor in ((100.0, 1e-12, 0.0), (150.0, 1e-5, 1e-4)):
+        kw = dict(nbNonzeroCoefs=1000, toleranceSnr=snr)
+        res = LoCOMP().computeCoefficientsBatch(np.stack([x, x]), D, **kw)
+        assert 'group' not in res.stop_reasons() and 'host' not in res.stop_reasons()
+        t = np.sort(res.coefficients[0].tocoo().row)
+        assert (np.searchsorted(t, t + W, side='right') - np.searchsorted(t, t - W)).max() > 135      # (groups beyond the LDS lists)
+        ch, rh = LoCOMP(refit='host').computeCoefficients(x, D, **kw)
+        a, h = res.coefficients[0].tocsc(), ch.tocsc()
+        scale = float(abs(h).max())
+        assert ((abs(a) > floor * scale) != (abs(h) > floor * scale)).nnz == 0, snr
+        assert float(abs(a - h).max()) <= tol * scale, snr
+        assert (res.coefficients[1] != res.coefficients[0]).nnz == 0
