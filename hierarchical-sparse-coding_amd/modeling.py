@@ -247,9 +247,19 @@ class ConvolutionalMatchingPursuit(SparseApproximator):
         if isinstance(innerProducts, _native.DeviceTable):
             # device-resident table: hand over the residual samples the atoms changed (the union of their supports),
             # the rows around every atom are recomputed where the table lives
-            spans = [centered_span(residual.shape[0], a.length, a.position)[:2] for a in atoms]
+            T = residual.shape[0]
+            spans = [centered_span(T, a.length, a.position)[:2] for a in atoms]
             lo, hi = min(s for s, _ in spans), max(e for _, e in spans)
             innerProducts.defer_update(residual, lo, hi, [a.position for a in atoms])
+            # Deferring is exact for rows that read the residual as it is: whatever a later atom of the round changes inside their
+            # windows it re-correlates itself.  Rows that read REFLECTED samples (:1046: a window that crosses a signal end) are not
+            # covered by that argument -- a later atom may change a sample they see through the reflection without re-correlating
+            # them, and the reference's table then keeps the value computed now (short signals, T < 3W - 2, are all edge).  Such
+            # an update goes to the device at once.
+            W = atoms[0].length if atoms else 0
+            off = (W - 1) // 2
+            if any(a.position - off - (W - 1) < 0 or a.position + W // 2 + (W - 1) > T - 1 for a in atoms):
+                innerProducts.flush()
             return innerProducts
         dt = _compute_dtype(innerProducts.dtype, D.dtype)
         if innerProducts.dtype != dt or not innerProducts.flags.c_contiguous:

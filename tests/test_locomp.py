@@ -489,3 +489,24 @@ def test_locomp_large_groups_down_to_round_off():
         assert ((abs(a) > floor * scale) != (abs(h) > floor * scale)).nnz == 0, snr
         assert float(abs(a - h).max()) <= tol * scale, snr
         assert (res.coefficients[1] != res.coefficients[0]).nnz == 0
+
+
+@pytest.mark.gpu
+def test_host_loop_sends_edge_updates_at_once():
+    """A one-atom dictionary of 14 taps on a 22-sample signal, eight blocks (draw 1353 of the fuzz sweep, found by tools/locomp_soak.py):
+    every re-correlation window crosses both signal ends, so the rows read reflected samples (modeling.py:1046) that LATER atoms of the
+    round change without re-correlating them -- the reference's table keeps the values computed at the time.  The host loop over the
+    device-resident table used to defer all updates of a round to its end (exact only for rows that read the residual as it is) and was
+    1e-2 off; an update whose window crosses an end now goes to the device at once.  With one atom in the dictionary LoCOMP has no
+    groups (:1241 drops entries of the same index), so the CPU oracle's greedy coder is the reference answer."""
+    import test_gpu_fuzz as fz
+    from oracle import hsc_oracle as orc
+    from hsc_amd.modeling import LoCOMP
+    x, D, kw = fz._draw(1353)
+    kw = dict(kw, nbNonzeroCoefs=40)
+    assert x.shape == (22,) and D.shape == (1, 14) and kw['nbBlocks'] == 8
+    co, ro, _ = orc.cmp_encode(x, D, **kw)
+    cd, rd = LoCOMP().computeCoefficients(x, D, **kw)
+    ch, rh = LoCOMP(refit='host').computeCoefficients(x, D, **kw)
+    assert float(abs(cd - co).max()) <= 1e-12 and float(abs(ch - co).max()) <= 1e-12
+    assert float(np.max(np.abs(rd - ro))) <= 1e-12 and float(np.max(np.abs(rh - ro))) <= 1e-12
