@@ -38,7 +38,8 @@ constexpr int kLocompLds = 64;        // ... whose Gram matrix stays in LDS (lar
 // atom beside all of its singletons, a group that fills its signal) comes out of LAPACK as an exact 0 or ~1e-17 and is cut in both
 // dtypes; a float32 group whose smallest singular value is mere round-off (1e-8 .. 1e-7 of the largest) is NOT cut there and the
 // reference's coefficients are that round-off amplified by 1e7 (measured: DESIGN.md section 7e) -- nothing reproduces those.
-constexpr double kLocompRankTol = 1e-13;
+constexpr double kLocompRankTol = 1e-14;      // x the largest diagonal entry: n u for the 64 .. 90 atoms of a large group (Higham's stopping rule);
+                                              // exact dependencies leave 0 .. 2e-16 there, the nearly singular group of fuzz draw 3613 (sigma_min / sigma_max = 6e-8) 6e-14
 
 template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
