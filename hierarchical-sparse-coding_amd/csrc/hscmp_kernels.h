@@ -970,6 +970,7 @@ template <typename R> struct GenericRecorr {
 template <typename R> struct LocompPre {
     int status, n, t, k, si; R a;       // status 2: lists + fitted coefficients ready; 3: also applied on a private copy of the residual:
     int u0, ulen; R loss; R span[4];    //   samples [u0, u0 + ulen) (lane l holds l, l + 64, ...) and the group's energy loss
+    int cell[2];                        //   (sparse dictionary instead: up to two cells per lane, their final values in span[0..1]; -1: none)
 };
 constexpr int kLocompSpacing = 4;      // x W + 4 samples between any two selections of a round that are computed side by side
 template <typename R, typename Pol, typename SH, typename SY>

@@ -210,6 +210,90 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
         sy.lds();
         return true;
     }
+    // The same pass for ONE selection by ONE wave, ahead of its application (locomp_precompute): nothing is written -- lane l leaves with
+    // the final values of the cells whose first pair is pair l or 64 + l, and the group's energy loss, summed exactly as group_update sums
+    // it (threads 0..63 and 64..127 of the workgroup as two trees, then (p0 + p1) + (0 + 0)).  At most 128 pairs; scratch: the wave's own
+    // LDS (off [n + 1], key / prod [128]).  Returns false when the lists are missing or too long: the application then runs group_update.
+    static __device__ __forceinline__ bool cells_ahead(const DevParams& P, const Sig<R>& G, const Args& A0, char* lds, int n, const int* gt, const int* gk,
+                                                       const double* ga, R c0, int* off, int* key, R* prod, int lane, int (&cell)[2], R (&val)[4], R& loss)
+    {
+        if (!A0.rl_cnt) return false;
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        if (!A.nzptr || A.rl_cap != 8) return false;
+        const int T = P.T, F = P.F;
+        auto wsync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        int cnt = 0;
+        if (lane < n) { const int kk = gk[lane]; cnt = A.nzptr[kk + 1] - A.nzptr[kk]; }
+        int incl = cnt;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m); if (lane >= m) incl += o; }
+        const int np = __shfl(incl, 63);
+        if (np > 128) return false;                           // uniform
+        if (lane < n) off[lane] = incl - cnt;
+        if (lane == 0) off[n] = np;
+        wsync();
+        for (int q = lane; q < np; q += 64) {
+            int lo = 0, hi = n;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= q) lo = mid; else hi = mid; }
+            const int gi = lo, kk = gk[gi], e = A.nzptr[kk] + (q - off[gi]);
+            const int wf = A.nzwf[e], f = wf & 0xffff, g = gt[gi] - P.off + (wf >> 16);
+            const R nc = -(n > 1 ? (R)ga[gi] : c0);
+            key[q] = (g >= 0 && g < T) ? g * F + f : -1 - q;
+            prod[q] = nc * A.nzval[e];
+        }
+        wsync();
+        R part[2] = {(R)0, (R)0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = lane + 64 * u;
+            cell[u] = -1; val[u] = (R)0;
+            if (q < np) {
+                const int cl = key[q];
+                bool first = cl >= 0;
+                for (int j = 0; j < q && first; ++j) first = key[j] != cl;
+                if (first) {
+                    const R vb = G.r[cl];
+                    R v = vb + prod[q];
+                    for (int j = q + 1; j < np; ++j) if (key[j] == cl) v = v + prod[j];
+                    const R sb = vb * vb, sa = v * v;
+                    part[u] = sb - sa;
+                    cell[u] = cl; val[u] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { part[0] = part[0] + __shfl_xor(part[0], m); part[1] = part[1] + __shfl_xor(part[1], m); }
+        const R z = (R)0;
+        loss = (part[0] + part[1]) + (z + z);
+        return true;
+    }
+    // ... and what is written when the selection is applied: the cells, and their entries in the row lists (as group_update does)
+    static __device__ __forceinline__ void commit_cells(const DevParams& P, const Sig<R>& G, const Args& A0, char* lds, const int (&cell)[2], const R (&val)[4])
+    {
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        const int T = P.T, F = P.F;
+        int* cntw = A.rl_cnt + (int64_t)blockIdx.x * T;
+        int* lfw = A.rl_f + (int64_t)blockIdx.x * T * 8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cl = cell[u];
+            if (cl < 0) continue;
+            const int g = cl / F, f = cl - g * F;
+            const int n2 = list_count(cntw + g);
+            const int4* row2 = reinterpret_cast<const int4*>(lfw + (int64_t)g * 8);
+            const int4 a2 = row2[0], b2 = row2[1];
+            G.r[cl] = val[u];
+            const bool listed = n2 > 8 || a2.x == f || a2.y == f || a2.z == f || a2.w == f || b2.x == f || b2.y == f || b2.z == f || b2.w == f;
+            if (!listed) {
+                const int o = atomicAdd(&cntw[g], 1);
+                if (o < 8) lfw[(int64_t)g * 8 + o] = f;
+            }
+        }
+    }
     static size_t policy_bytes(const DevParams& P, const Args& A) { return ((Base::extra_lds_bytes(P, A) + 15) / 16) * 16; }
     static size_t extra_lds_bytes(const DevParams& P, const Args& A) { return policy_bytes(P, A) + sizeof(LocompLds<R>) + 16; }
     static __device__ __forceinline__ LocompLds<R>& group(const DevParams& P, const Args& A, char* lds)
@@ -644,7 +728,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
     typename Pol::Lds& L = Pol::group(P, A, plds);
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
     pre.status = 0; pre.n = 0; pre.t = 0; pre.k = 0; pre.si = -1; pre.a = (R)0; pre.u0 = 0; pre.ulen = 0; pre.loss = (R)0;
-    pre.span[0] = pre.span[1] = pre.span[2] = pre.span[3] = (R)0;
+    pre.span[0] = pre.span[1] = pre.span[2] = pre.span[3] = (R)0; pre.cell[0] = pre.cell[1] = -1;
     auto wave_sync = [&]() {                                     // LDS written by a lane of this wave, read by another one
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -749,6 +833,20 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                 pre.status = 2; pre.n = n;
                 if (lane < n) { pre.t = w.t[lane]; pre.k = w.k[lane]; pre.si = w.si[lane]; pre.a = n > 1 ? (R)w.b[lane] : c; }
             }
+            // Sparse dictionary with row lists: the group's cells and its energy loss too (LocompSparse::cells_ahead), in the LDS the normal
+            // equations have left; applied by the owning wave when the selection's turn comes.
+            if constexpr (Pol::kGroupUpdate) {
+                if (ok) {
+                    static_assert(sizeof(w.g) >= 33 * sizeof(int) + 128 * (sizeof(int) + sizeof(R)) + 16, "the pair lists live in the Gram matrix's LDS");
+                    int* off = reinterpret_cast<int*>(w.g);
+                    R* prod = reinterpret_cast<R*>(reinterpret_cast<char*>(w.g) + ((33 * sizeof(int) + 15) & ~(size_t)15));
+                    int* key = reinterpret_cast<int*>(prod + 128);
+                    R loss;
+                    if (Pol::cells_ahead(P, G, A, plds, n, w.t, w.k, w.b, c, off, key, prod, lane, pre.cell, pre.span, loss)) {
+                        pre.status = 3; pre.loss = loss;
+                    }
+                }
+            }
             // Dense dictionary, short atoms: the group's subtractions too, on a PRIVATE copy of the stretch of the residual they touch
             // (in the LDS the normal equations have left; at most 256 samples, which then travel in four registers per lane) -- atom
             // after atom with the local energies of :996-1016, the same products, sums and trees as apply on the residual itself.
@@ -843,10 +941,13 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
                     if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; full = true; }
                 }
                 full = __shfl(full ? 1 : 0, 0) != 0;
-                if (st == 3 && !full) {                          // the residual of the group's span, as its atoms left it on the private copy
-                    R* dst = G.r + (int64_t)pre.u0 * F;
+                if (st == 3 && !full) {
+                    if constexpr (Pol::kGroupUpdate) Pol::commit_cells(P, G, A, plds, pre.cell, pre.span);      // the group's cells and their row-list entries
+                    else {                                       // the residual of the group's span, as its atoms left it on the private copy
+                        R* dst = G.r + (int64_t)pre.u0 * F;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; if (i < pre.ulen) dst[i] = pre.span[u]; }
+                        for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; if (i < pre.ulen) dst[i] = pre.span[u]; }
+                    }
                 }
             }
             if (lane == 0) L.status = st;
