@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         int lc_first = 0, lc_count = 0;
         LocompPre<R> lc_pre{};
         if constexpr (Recorr::kLocomp) {
-            if (P.blocked && nsel >= 2 && !P.select_only && P.lc_ahead) {
+            if (P.blocked && nsel >= 2 && !P.select_only && (P.lc_ahead & 1)) {
                 int bad = 0;
                 for (int e = tid; e < nsel * nsel; e += kThreads) {
                     const int i = e / nsel, j = e - i * nsel;

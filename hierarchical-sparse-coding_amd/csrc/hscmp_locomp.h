@@ -25,6 +25,7 @@
 #include "hscmp_kernels.h"
 #include "hscmp_mfma.h"
 #include "hscmp_sparse.h"
+#include "hscmp_rp_sparse.h"
 
 namespace hscmp {
 
@@ -115,6 +116,32 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
     {
         const SparseLds<R> L = sparse_lds_view<R>(lds, A0.caps);
         const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        // Row lists and by-feature dictionary lists at hand: the union of the group's rows in FOUR parts, one wave each, through the
+        // per-wave window gather / pairing / sort / chains of the round-parallel level loop (RpSparse::rows_listed: the same pinned
+        // chains, the same per-row arg-max) -- the workgroup-wide sparse_rows below walks the rows 2W - 1 at a time with a dozen
+        // barriers per pass.  The four slots are carved out of the policy's own LDS lists (nothing else uses them between two atoms).
+        if (A0.rl_cnt && A.rl_cap == 8 && A.fptr && A.nzptr && (P.lc_ahead & 2)) {          // uniform
+            const size_t sb = (sparse_lds_bytes<R>(A0.caps) / kWaves) & ~(size_t)15;
+            RpSparseCaps c{};
+            c.nz = A0.caps.nz >= 512 ? 128 : 64;
+            c.rec = (int)((sb - 16 - (size_t)c.nz * (sizeof(R) + 4)) / (8 + 3 * sizeof(R) + 8)) & ~7;
+            if (sb > 16 + (size_t)c.nz * (sizeof(R) + 4) && c.rec >= 64) {
+                const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
+                const RpSparseSlot<R> SL = rp_sparse_slot<R>(lds + (size_t)wv * sb, c);
+                const int nrows = (pmax - pmin) + 2 * P.W - 1, pbase = pmin;          // (row 0 = position pmin - (W - 1))
+                const int per = (nrows + kWaves - 1) / kWaves;
+                const int rb = wv * per, re = min(nrows, rb + per);
+                int step = min(max(re - rb, 1), c.rec);
+                for (int r0 = rb; r0 < re;) {
+                    const int nr = min(step, re - r0);
+                    if (RpSparse<R>::rows_listed(P, G, A, SL, c, pbase, r0, nr, true, 0, 0, lane)) { r0 += nr; continue; }
+                    if (nr > 1) { step = (nr + 1) / 2; continue; }
+                    RpSparse<R>::row_by_atoms(P, G, A, pbase, r0, true, 0, 0, lane);
+                    r0 += 1;
+                }
+                return;                                                  // (the caller's barrier follows)
+            }
+        }
         unsigned* bits = Base::has_bits(P, A) ? Base::bits_of(P, A0, lds) : nullptr;
         if (bits) {                                          // (no row lists: the rows the group's subtractions may have filled)
             const int lo = max(0, pmin - (P.W - 1) / 2), hi = min(P.T, pmax + P.W / 2 + 1);

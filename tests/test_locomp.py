@@ -441,7 +441,8 @@ def test_table_calls_without_open_table_fail_loudly():
 def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case, monkeypatch):
     """Blocked rounds whose selections lie more than 4W + 4 samples apart get neighbourhood, normal equations, re-fit (and, with a dense
     dictionary, the subtractions on a private copy of the span) of up to four selections computed at once, one wave each, before they
-    are applied in order (locomp_precompute).  HSCMP_LOCOMP_AHEAD=0 applies the same rounds selection by selection: every signal of
+    are applied in order (locomp_precompute), and on sparse dictionaries the rows of a group are re-correlated one wave per quarter
+    (RpSparse::rows_listed).  HSCMP_LOCOMP_AHEAD=0 applies the same rounds selection by selection, workgroup-wide: every signal of
     every policy bit for bit -- long signals with few blocks so that the rounds really are spaced."""
     from hsc_amd.modeling import LoCOMP
     T, K, W, F, dtype, natoms, kw, sp = BATCH_CASES[case]
@@ -455,9 +456,12 @@ def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case,
         kw['nbNonzeroCoefs'] = 8 * kw['nbNonzeroCoefs']
     rs = np.random.RandomState(case)
     xs = np.stack([x, (0.5 * x).astype(dtype), x[::-1].copy(), (x + 0.02 * rs.standard_normal(x.shape)).astype(dtype)])
-    ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+    ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)           # (default: both on -- HSCMP_LOCOMP_AHEAD=3)
+    monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '1')                    # side by side, but a group's rows by the whole workgroup
+    only_ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
     monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '0')
     seq = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
+    assert np.array_equal(only_ahead.stats, seq.stats) and np.array_equal(only_ahead.residuals, seq.residuals)
     assert np.array_equal(ahead.stats, seq.stats) and np.array_equal(ahead.energies, seq.energies)
     assert int(ahead.stats[:, 4].sum()) > 4 * xs.shape[0]          # (several selections per signal)
     for b in range(xs.shape[0]):
