@@ -367,8 +367,9 @@ static int make_params_g(hscmp_ctx* ctx, int K, int W, int F, int B, int T, cons
     P.max_rounds = p->max_rounds;
     P.lg_cap = kLocompGroupCap;
     if (const char* v = getenv("HSCMP_LOCOMP_GROUP_CAP")) P.lg_cap = std::min(4096, std::max(2, atoi(v)));
-    P.lc_ahead = 3;          // bit 0: selections of a round side by side; bit 1: a group's rows re-correlated one wave per quarter (sparse policy)
-    if (const char* v = getenv("HSCMP_LOCOMP_AHEAD")) P.lc_ahead = atoi(v) & 3;
+    P.lc_ahead = 7;          // bit 0: selections of a round side by side; bit 1: a group's rows re-correlated one wave per quarter (sparse policy);
+                             // bit 2: the rows of a batch of selections re-correlated behind its last one, one wave per selection
+    if (const char* v = getenv("HSCMP_LOCOMP_AHEAD")) P.lc_ahead = atoi(v) & 7;
     *out = P;
     return HSCMP_OK;
 }

@@ -197,7 +197,7 @@ struct DevParams {
     int max_rounds;     // <= 0: until converged
     int select_only;    // 1: run ONE selection (modeling.py:899-982), hand the atoms back, apply nothing
     int lg_cap;         // LoCOMP: atoms of the largest group the signal's global scratch holds (lgram_doubles; larger: STOP_GROUP)
-    int lc_ahead;       // LoCOMP: bit 0 = the selections of a round that lie far enough apart are computed side by side, bit 1 = a group's rows
+    int lc_ahead;       // LoCOMP: bit 2 = the rows of a batch of selections re-correlated behind its last one; bit 0 = the selections of a round that lie far enough apart are computed side by side, bit 1 = a group's rows
                         // re-correlated one wave per quarter on sparse dictionaries (hscmp_locomp.h; HSCMP_LOCOMP_AHEAD)
 };
 

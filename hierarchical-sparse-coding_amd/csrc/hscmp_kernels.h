@@ -972,10 +972,16 @@ template <typename R> struct LocompPre {
     int u0, ulen; R loss; R span[4];    //   samples [u0, u0 + ulen) (lane l holds l, l + 64, ...) and the group's energy loss
     int cell[2];                        //   (sparse dictionary instead: up to two cells per lane, their final values in span[0..1]; -1: none)
 };
-constexpr int kLocompSpacing = 4;      // x W + 4 samples between any two selections of a round that are computed side by side
+constexpr int kLocompSpacing = 5;      // x W + 8 samples between any two selections of a round that are computed side by side
+// the rows of a selection whose re-correlation waits for the end of its batch (the owning wave's registers)
+struct LocompRows { int pending, pmin, pmax; };
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner);      // true: taken from `pre`
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner,
+                                            bool may_defer, LocompRows& rows);      // true: the re-correlation of its rows was deferred
+template <typename R, typename Pol, typename SY>
+__device__ __forceinline__ void locomp_rows_deferred(const DevParams& P, const State<R>& S, const Sig<R>& G, const typename Pol::Args& A, char* plds,
+                                                     LocompRows& rows, SY& sy);
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
                                                   const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy);
@@ -1314,14 +1320,17 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         bool lc_spaced = false;
         int lc_first = 0, lc_count = 0;
         LocompPre<R> lc_pre{};
+        LocompRows lc_rows{0, 0, 0};
+        bool lc_defer = false, lc_waiting = false;       // uniform: this policy's state allows deferred rows; some wave holds rows that wait
         if constexpr (Recorr::kLocomp) {
             if (P.blocked && nsel >= 2 && !P.select_only && (P.lc_ahead & 1)) {
                 int bad = 0;
                 for (int e = tid; e < nsel * nsel; e += kThreads) {
                     const int i = e / nsel, j = e - i * nsel;
-                    if (i < j && abs(ord_t[i] - ord_t[j]) <= kLocompSpacing * W + 4) bad = 1;
+                    if (i < j && abs(ord_t[i] - ord_t[j]) <= kLocompSpacing * W + 8) bad = 1;
                 }
                 lc_spaced = sy.count(bad) == 0;
+                lc_defer = lc_spaced && (P.lc_ahead & 4) && Recorr::can_defer_rows(P, A, plds);
             }
         }
         for (int ai = 0; ai < nsel; ++ai) {
@@ -1345,8 +1354,16 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                     locomp_precompute<R, Recorr>(P, S, G, sh, A, plds, ord_t, ord_k, ord_c, lc_first, lc_count, lc_pre, sy);
                 }
                 const bool ahead = lc_spaced && ai >= lc_first && ai < lc_first + lc_count;
-                (void)locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1);
-                if (sh.skip || sh.converged) break;
+                // the rows of the selections of a batch are re-correlated TOGETHER behind its last one, one wave per selection: nothing a
+                // later selection of the batch reads or writes lies within the rows of an earlier one, or within the samples they are formed from
+                if (locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1, ahead && lc_defer, lc_rows))
+                    lc_waiting = true;
+                const bool leave = sh.skip || sh.converged;              // (uniform: read behind the atom's last barrier)
+                if (lc_waiting && (leave || ai == lc_first + lc_count - 1 || ai == nsel - 1)) {
+                    locomp_rows_deferred<R, Recorr>(P, S, G, A, plds, lc_rows, sy);
+                    lc_waiting = false;
+                }
+                if (leave) break;
                 continue;
             }
 

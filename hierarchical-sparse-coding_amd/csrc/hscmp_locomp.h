@@ -45,6 +45,7 @@ constexpr double kLocompRankTol = 1e-14;      // x the largest diagonal entry: n
 template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
     int status, pad_;                 // 2: the lists and fitted coefficients were computed ahead (locomp_precompute)
+    int jmin, jmax, jout, pad2_;      // first / last position of the group; an atom whose rows reach beyond the signal (their rows are re-correlated together otherwise)
     int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
     int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
     R a[NMAX];                  // fitted coefficients in the dictionary's dtype (:1329)
@@ -66,6 +67,7 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
     static constexpr bool kGroupUpdate = false;
     static constexpr int kFastGroup = LocompLds<R>::kFastGroup;
     static constexpr bool kUnionRows = false;
+    static constexpr bool kLoneRows = false;
     static constexpr bool kOwnInit = false;
     static constexpr int kMaxGroup = kLocompMax;
     using Lds = LocompLds<R>;
@@ -83,6 +85,8 @@ template <typename R> struct LocompRecorr : GenericRecorr<R> {
         return *reinterpret_cast<LocompLds<R>*>(lds + ((Base::kWinBytes + 15) / 16) * 16);
     }
     static __device__ __forceinline__ void before_runs(const Args&, char*) {}
+    static __device__ __forceinline__ bool can_defer_rows(const DevParams&, const Args&, char*) { return false; }
+    static __device__ __forceinline__ void rows_of_wave(const DevParams&, const State<R>&, const Sig<R>&, const Args&, char*, int, int) {}
 };
 
 // the same on the sparse policy (multi-feature inputs, sparse dictionary: hierarchical levels >= 1): the residual update keeps
@@ -94,6 +98,7 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
                                                         //  this policy has the registers for the whole LDS-resident range; lane n holds b)
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = true;
+    static constexpr bool kLoneRows = false;            // (a lone atom goes through the workgroup-wide rows with the window copy its subtraction left)
     static constexpr int kMaxGroup = kLocompMax;
     using Lds = LocompLds<R>;
     using Base = SparseRecorr<R, false>;
@@ -109,6 +114,46 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
         nzptr = A.nzptr; nzwf = A.nzwf; nzval = A.nzval;
         return A.nzptr != nullptr;
     }
+    // the four per-wave slots of the round-parallel loop's row pipeline, carved out of the policy's own LDS lists (nothing else uses them
+    // between two atoms): available with row lists and by-feature dictionary lists at hand
+    static __device__ __forceinline__ bool wave_slots(const Args& A0, const Args& A, size_t& sb, RpSparseCaps& c)
+    {
+        if (!(A0.rl_cnt && A.rl_cap == 8 && A.fptr && A.nzptr)) return false;
+        sb = (sparse_lds_bytes<R>(A0.caps) / kWaves) & ~(size_t)15;
+        c.nz = A0.caps.nz >= 512 ? 128 : 64;
+        if (sb <= 16 + (size_t)c.nz * (sizeof(R) + 4)) return false;
+        c.rec = (int)((sb - 16 - (size_t)c.nz * (sizeof(R) + 4)) / (8 + 3 * sizeof(R) + 8)) & ~7;
+        return c.rec >= 64;
+    }
+    // rows [rb, re) of the union that starts at position pbase - (W - 1), by the calling wave in its own slot
+    static __device__ __forceinline__ void rows_by_wave(const DevParams& P, const Sig<R>& G, const Args& A, char* lds, size_t sb, const RpSparseCaps& c,
+                                                        int pbase, int rb, int re)
+    {
+        const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
+        const RpSparseSlot<R> SL = rp_sparse_slot<R>(lds + (size_t)wv * sb, c);
+        int step = min(max(re - rb, 1), c.rec);
+        for (int r0 = rb; r0 < re;) {
+            const int nr = min(step, re - r0);
+            if (RpSparse<R>::rows_listed(P, G, A, SL, c, pbase, r0, nr, true, 0, 0, lane)) { r0 += nr; continue; }
+            if (nr > 1) { step = (nr + 1) / 2; continue; }
+            RpSparse<R>::row_by_atoms(P, G, A, pbase, r0, true, 0, 0, lane);
+            r0 += 1;
+        }
+    }
+    // deferred rows (locomp_rows_deferred): ALL rows of one selection's group by the wave that owns it
+    static __device__ __forceinline__ bool can_defer_rows(const DevParams& P, const Args& A0, char* lds)
+    {
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        size_t sb; RpSparseCaps c{};
+        return (P.lc_ahead & 2) && wave_slots(A0, A, sb, c);
+    }
+    static __device__ __forceinline__ void rows_of_wave(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A0, char* lds, int pmin, int pmax)
+    {
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        size_t sb; RpSparseCaps c{};
+        wave_slots(A0, A, sb, c);
+        rows_by_wave(P, G, A, lds, sb, c, pmin, 0, (pmax - pmin) + 2 * P.W - 1);
+    }
     // the rows of a group of interior atoms between pmin and pmax, once: 2W-1 rows at a time (the capacity of sparse_rows), no
     // padding involved (every window lies inside the signal)
     template <typename SY>
@@ -120,27 +165,13 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
         // per-wave window gather / pairing / sort / chains of the round-parallel level loop (RpSparse::rows_listed: the same pinned
         // chains, the same per-row arg-max) -- the workgroup-wide sparse_rows below walks the rows 2W - 1 at a time with a dozen
         // barriers per pass.  The four slots are carved out of the policy's own LDS lists (nothing else uses them between two atoms).
-        if (A0.rl_cnt && A.rl_cap == 8 && A.fptr && A.nzptr && (P.lc_ahead & 2)) {          // uniform
-            const size_t sb = (sparse_lds_bytes<R>(A0.caps) / kWaves) & ~(size_t)15;
-            RpSparseCaps c{};
-            c.nz = A0.caps.nz >= 512 ? 128 : 64;
-            c.rec = (int)((sb - 16 - (size_t)c.nz * (sizeof(R) + 4)) / (8 + 3 * sizeof(R) + 8)) & ~7;
-            if (sb > 16 + (size_t)c.nz * (sizeof(R) + 4) && c.rec >= 64) {
-                const int tid = ltid(), lane = tid & 63, wv = tid >> 6;
-                const RpSparseSlot<R> SL = rp_sparse_slot<R>(lds + (size_t)wv * sb, c);
-                const int nrows = (pmax - pmin) + 2 * P.W - 1, pbase = pmin;          // (row 0 = position pmin - (W - 1))
-                const int per = (nrows + kWaves - 1) / kWaves;
-                const int rb = wv * per, re = min(nrows, rb + per);
-                int step = min(max(re - rb, 1), c.rec);
-                for (int r0 = rb; r0 < re;) {
-                    const int nr = min(step, re - r0);
-                    if (RpSparse<R>::rows_listed(P, G, A, SL, c, pbase, r0, nr, true, 0, 0, lane)) { r0 += nr; continue; }
-                    if (nr > 1) { step = (nr + 1) / 2; continue; }
-                    RpSparse<R>::row_by_atoms(P, G, A, pbase, r0, true, 0, 0, lane);
-                    r0 += 1;
-                }
-                return;                                                  // (the caller's barrier follows)
-            }
+        size_t sb; RpSparseCaps c{};
+        if ((P.lc_ahead & 2) && wave_slots(A0, A, sb, c)) {              // uniform
+            const int wv = ltid() >> 6;
+            const int nrows = (pmax - pmin) + 2 * P.W - 1;               // (row 0 = position pmin - (W - 1))
+            const int per = (nrows + kWaves - 1) / kWaves;
+            rows_by_wave(P, G, A, lds, sb, c, pmin, wv * per, min(nrows, wv * per + per));
+            return;                                                      // (the caller's barrier follows)
         }
         unsigned* bits = Base::has_bits(P, A) ? Base::bits_of(P, A0, lds) : nullptr;
         if (bits) {                                          // (no row lists: the rows the group's subtractions may have filled)
@@ -432,6 +463,7 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     // rows of one re-correlation: 2W-1 around one atom, or the union over a group of interior atoms -- their positions lie within
     // [p - W, p + W] of the selected atom (:1228-1236), so at most 4W-1 rows
     static constexpr bool kUnionRows = true;
+    static constexpr bool kLoneRows = true;             // (an interior atom on its own: lrun_span's rows are lrun's)
     static __host__ __device__ int max_tiles(int W) { return (4 * W - 1 + TP - 1) / TP; }
     static __host__ __device__ int win_floats(int W) { return max_tiles(W) * TP + 8 * S4C + 32; }        // (a multiple of 4)
     static __host__ __device__ size_t front_bytes(int W) { return ((size_t)win_floats(W) * sizeof(float) + 15) / 16 * 16; }
@@ -529,6 +561,29 @@ template <int S4C, bool HAS_W, int GS = 1> struct LocompMfma {
     static __device__ __forceinline__ void lrun_span(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax, Sync& sy)
     {
         rows(P, G, A, lds, pmin - (P.W - 1), (pmax - pmin) + 2 * P.W - 1, true, 0, 0, sy, true);
+    }
+    // deferred rows (locomp_rows_deferred): the same rows by ONE wave -- its window in the wave's quarter of the group state (idle between
+    // two batches), its tiles one after the other
+    static constexpr size_t kWaveStride = (sizeof(Lds) / kWaves) & ~(size_t)15;
+    static __device__ __forceinline__ bool can_defer_rows(const DevParams& P, const Args&, char*) { return (size_t)win_floats(P.W) * sizeof(float) <= kWaveStride; }
+    static __device__ __forceinline__ void rows_of_wave(const DevParams& P, const State<R>&, const Sig<R>& G, const Args& A, char* lds, int pmin, int pmax)
+    {
+        const Lay L = layout(P, A, lds);
+        const int W = P.W, tid = ltid(), lane = tid & 63, wv = tid >> 6;
+        const int t0 = pmin - (W - 1), nrows = (pmax - pmin) + 2 * W - 1;
+        const int span = nrows + W - 1, wstart = t0 - P.off;
+        float* win = reinterpret_cast<float*>(reinterpret_cast<char*>(&group(P, A, lds)) + (size_t)wv * kWaveStride);
+        for (int i = lane; i < L.wf; i += 64) win[i] = i < span ? G.r[wstart + i] : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nt = (nrows + TP - 1) / TP;
+        for (int q = 0; q < nt; ++q) {
+            float c; int k;
+            mfma_tile_best<S4C, HAS_W>(L.dimg, win + TP * q, L.wts, A.G, P.K, lane, c, k);
+            const int row = TP * q + lane;
+            if (lane < TP && row < nrows) { G.bc[t0 + row] = c; G.bk[t0 + row] = k; }       // (interior atoms: every row lies inside the signal)
+        }
     }
     // (the step-by-step atom body of the greedy loop is never instantiated for a kLocomp policy, but must compile)
     template <typename SH>
@@ -728,6 +783,22 @@ __device__ __attribute__((noinline)) bool locomp_fast_solve(unsigned g_off, unsi
     return true;
 }
 
+// sum over x = sub, sub + 8, ... < cnt of a[x] * b[x] in float64, x ascending (one lane of the eight that share an item of the normal
+// equations): the loads of four steps are issued together -- one memory round trip instead of four -- the sums stay in order
+template <typename R>
+__device__ __forceinline__ double strided8_dot(const R* __restrict__ a, const R* __restrict__ b, int sub, int cnt)
+{
+    double acc = 0.0;
+    for (int x0 = sub; x0 < cnt; x0 += 32) {
+        R av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int x = x0 + 8 * u; av[u] = (R)0; bv[u] = (R)0; if (x < cnt) { av[u] = a[x]; bv[u] = b[x]; } }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (x0 + 8 * u < cnt) acc += (double)av[u] * (double)bv[u];
+    }
+    return acc;
+}
+
 // ---- the selections of a blocked round side by side, as far as they do not depend on each other -------------------------------
 // The atoms of a blocked round (:908-963) are applied one after the other (:1314), but when they lie more than 4W + 4 samples apart
 // nothing one of them does reaches what another one's neighbourhood, normal equations and re-fit read: neighbours come from positions
@@ -832,7 +903,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                             const int len = centered_span(T, W, w.t[it], s_, e_, es_);
                             const R* dk = S.D + ((int64_t)w.k[it] * W + es_) * F;
                             const R* rv = G.r + (int64_t)s_ * F;
-                            for (int x = sub; x < len * F; x += 8) acc += (double)dk[x] * (double)rv[x];
+                            acc = strided8_dot(dk, rv, sub, len * F);
                         } else {
                             tri_decode(it - n, i, j);
                             int si_, ei_, esi, sj_, ej_, esj;
@@ -842,7 +913,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                             if (hi > lo) {
                                 const R* di = S.D + ((int64_t)w.k[i] * W + (lo - si_ + esi)) * F;
                                 const R* dj = S.D + ((int64_t)w.k[j] * W + (lo - sj_ + esj)) * F;
-                                for (int x = sub; x < (hi - lo) * F; x += 8) acc += (double)di[x] * (double)dj[x];
+                                acc = strided8_dot(di, dj, sub, (hi - lo) * F);
                             }
                         }
                         acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
@@ -890,31 +961,39 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                         for (int i = lane; i < ulen; i += 64) cp[i] = src[i];
                         wave_sync();
                         R loss = (R)0;
+                        // (an atom's elements are fetched while its predecessor is applied: cnt <= ulen <= 256, four per lane)
+                        R dn[4];
+                        auto fetch_atom = [&](int gi) {
+                            int s, e, es;
+                            const int cnt = centered_span(T, W, w.t[gi], s, e, es) * F;
+                            const R* dk = S.D + ((int64_t)w.k[gi] * W + es) * F;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; dn[u] = i < cnt ? dk[i] : (R)0; }
+                        };
+                        fetch_atom(0);
                         for (int gi = 0; gi < n; ++gi) {
-                            const int tp = w.t[gi], kk = w.k[gi];
+                            const int tp = w.t[gi];
                             const R cf = n > 1 ? (R)w.b[gi] : c;
                             int s, e, es;
                             const int cnt = centered_span(T, W, tp, s, e, es) * F;
                             const R nc = -cf;
-                            const R* dk = S.D + ((int64_t)kk * W + es) * F;
                             R* rv = cp + (s - u0) * F;
                             R b4[4] = {(R)0, (R)0, (R)0, (R)0}, a4[4] = {(R)0, (R)0, (R)0, (R)0};
-                            for (int i0 = lane; i0 < cnt; i0 += kThreads) {
-                                R v[4], d[4];
+                            R v[4], d[4];
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = (R)0; d[u] = (R)0; if (i < cnt) { v[u] = rv[i]; d[u] = dk[i]; } }
+                            for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; d[u] = dn[u]; v[u] = i < cnt ? rv[i] : (R)0; }
+                            if (gi + 1 < n) fetch_atom(gi + 1);
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int i = i0 + 64 * u;
-                                    if (i < cnt) {
-                                        const R sq = v[u] * v[u];
-                                        b4[u] = b4[u] + sq;
-                                        const R prod = nc * d[u];            // -c*D[k] rounded, then += (utils.py:120,129)
-                                        const R vn = v[u] + prod;
-                                        rv[i] = vn;
-                                        const R sq2 = vn * vn;
-                                        a4[u] = a4[u] + sq2;
-                                    }
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = lane + 64 * u;
+                                if (i < cnt) {
+                                    const R sq = v[u] * v[u];
+                                    b4[u] = b4[u] + sq;
+                                    const R prod = nc * d[u];            // -c*D[k] rounded, then += (utils.py:120,129)
+                                    const R vn = v[u] + prod;
+                                    rv[i] = vn;
+                                    const R sq2 = vn * vn;
+                                    a4[u] = a4[u] + sq2;
                                 }
                             }
 #pragma unroll
@@ -948,7 +1027,8 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner)
+                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner,
+                                            bool may_defer, LocompRows& rows)
 {
     const int T = P.T, W = P.W, F = P.F, tid = ltid(), lane = tid & 63, wv = tid >> 6;
     typename Pol::Lds& L = Pol::group(P, A, plds);
@@ -965,6 +1045,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
                 bool full = false;
                 if (lane == 0) {
                     L.n = pre.n; L.cnt = pre.n - 1; L.loss = st == 3 ? pre.loss : (R)0; L.last_e = sh.e_res;
+                    L.jmin = INT_MAX; L.jmax = INT_MIN; L.jout = 0;
                     if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; full = true; }
                 }
                 full = __shfl(full ? 1 : 0, 0) != 0;
@@ -989,6 +1070,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
         if (tid == 0) {
             if (sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; }
             L.cnt = 0; L.t[0] = p; L.k[0] = k; L.si[0] = -1; L.loss = (R)0; L.last_e = sh.e_res;
+            L.jmin = INT_MAX; L.jmax = INT_MIN; L.jout = 0;
         }
         sy.full();
         if (sh.skip) return false;
@@ -1125,7 +1207,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
                     const int len = centered_span(T, W, T_(it), s_, e_, es_);
                     const R* dk = S.D + ((int64_t)K_(it) * W + es_) * F;
                     const R* rv = G.r + (int64_t)s_ * F;
-                    for (int x = sub; x < len * F; x += 8) acc += (double)dk[x] * (double)rv[x];
+                    acc = strided8_dot(dk, rv, sub, len * F);
                 } else {
                     tri_decode(it - n, i, j);
                     int si_, ei_, esi, sj_, ej_, esj;
@@ -1135,7 +1217,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
                     if (hi > lo) {
                         const R* di = S.D + ((int64_t)K_(i) * W + (lo - si_ + esi)) * F;
                         const R* dj = S.D + ((int64_t)K_(j) * W + (lo - sj_ + esj)) * F;
-                        for (int x = sub; x < (hi - lo) * F; x += 8) acc += (double)di[x] * (double)dj[x];
+                        acc = strided8_dot(di, dj, sub, (hi - lo) * F);
                     }
                 }
                 acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
@@ -1364,6 +1446,10 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
         }
         const int d = (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
         if (d) atomicAdd(&sh.nnz, d);
+        if constexpr (Pol::kUnionRows) {                                                // (read behind the barriers below)
+            atomicMin(&L.jmin, tp); atomicMax(&L.jmax, tp);
+            if (!(tp - P.off - (W - 1) >= 0 && tp + W / 2 + (W - 1) <= T - 1)) L.jout = 1;     // interior: no padding in its rows (:1028-1046)
+        }
     }
     // A policy that knows the cells of its atoms (sparse dictionary, row lists) applies the whole group in one pass
     bool grouped = false;
@@ -1478,32 +1564,36 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
     // ---- :1353 re-correlation around every atom of the group (from the final residual), then the maxima of their segments
     Pol::before_runs(A, plds);
     sy.full();
-    bool joint = Pol::kUnionRows && n > 1;
+    bool joint = false;
     int pmin = p, pmax = p;
-    if (joint)
-        for (int gi = 0; gi < n; ++gi) {                               // uniform
-            const int tp = T_(gi);
-            joint = joint && tp - P.off - (W - 1) >= 0 && tp + W / 2 + (W - 1) <= T - 1;      // interior: no padding in its rows (:1028-1046)
-            pmin = min(pmin, tp); pmax = max(pmax, tp);
-        }
+    if constexpr (Pol::kUnionRows) { joint = (n > 1 || Pol::kLoneRows) && L.jout == 0; pmin = L.jmin; pmax = L.jmax; }       // uniform
+    bool deferred = false;
     if (joint && pmax - pmin <= 2 * W) {
-        Pol::lrun_span(P, S, G, A, plds, pmin, pmax, sy);
-        sy.full();
+        if (may_defer && owner >= 0) {                                   // uniform: the owning wave does them behind the batch's last selection
+            if (wv == owner) { rows.pending = 1; rows.pmin = pmin; rows.pmax = pmax; }
+            deferred = true;
+        } else {
+            Pol::lrun_span(P, S, G, A, plds, pmin, pmax, sy);
+            sy.full();
+        }
     } else
     for (int gi = 0; gi < n; ++gi) {
         Pol::lrun(P, S, G, sh, A, plds, T_(gi), K_(gi), sy);
         sy.full();
     }
     HSCMP_STAMP(5);                                                      // re-correlation
+    if (P.blocked) {                                                     // the round end rescans the marked segments: one thread per atom
+        for (int gi = tid; gi < n; gi += kThreads) {
+            const int tp = T_(gi);
+            const int sg0 = max(0, tp - (W - 1)) >> P.seg_shift, sg1 = min(T - 1, tp + (W - 1)) >> P.seg_shift;
+            for (int sg = sg0; sg <= sg1; ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
+        }
+    } else
     for (int gi = 0; gi < n; ++gi) {
         const int tp = T_(gi);
         const int lo = max(0, tp - (W - 1)), hi = min(T - 1, tp + (W - 1));
         const int sg0 = lo >> P.seg_shift, sg1 = hi >> P.seg_shift;
-        if (P.blocked) {
-            if (tid == (gi & (kThreads - 1))) for (int sg = sg0; sg <= sg1; ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
-        } else {
-            for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<false>(P, G, wts, sh, sg, lane);
-        }
+        for (int sg = sg0 + wv; sg <= sg1; sg += kWaves) scan_segment<false>(P, G, wts, sh, sg, lane);
     }
 
     // ---- :1357-1383 fast stop rules
@@ -1525,7 +1615,17 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
         }
     }
     sy.full();
-    return have;
+    return deferred;
+}
+
+// the rows that waited (locomp_atom, may_defer): every wave those of the selection it owns, side by side; all threads of the workgroup
+template <typename R, typename Pol, typename SY>
+__device__ __forceinline__ void locomp_rows_deferred(const DevParams& P, const State<R>& S, const Sig<R>& G, const typename Pol::Args& A, char* plds,
+                                                     LocompRows& rows, SY& sy)
+{
+    if (rows.pending) Pol::rows_of_wave(P, S, G, A, plds, rows.pmin, rows.pmax);
+    rows.pending = 0;
+    sy.full();
 }
 
 }  // namespace hscmp

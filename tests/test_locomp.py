@@ -439,9 +439,10 @@ def test_table_calls_without_open_table_fail_loudly():
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', range(len(BATCH_CASES)))
 def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case, monkeypatch):
-    """Blocked rounds whose selections lie more than 4W + 4 samples apart get neighbourhood, normal equations, re-fit (and, with a dense
+    """Blocked rounds whose selections lie more than 5W + 8 samples apart get neighbourhood, normal equations, re-fit (and, with a dense
     dictionary, the subtractions on a private copy of the span) of up to four selections computed at once, one wave each, before they
-    are applied in order (locomp_precompute), and on sparse dictionaries the rows of a group are re-correlated one wave per quarter
+    are applied in order (locomp_precompute); the rows of such a batch are re-correlated behind its last selection, one wave per
+    selection (locomp_rows_deferred), and on sparse dictionaries the rows of a group that does not wait go one wave per quarter
     (RpSparse::rows_listed).  HSCMP_LOCOMP_AHEAD=0 applies the same rounds selection by selection, workgroup-wide: every signal of
     every policy bit for bit -- long signals with few blocks so that the rounds really are spaced."""
     from hsc_amd.modeling import LoCOMP
@@ -456,12 +457,15 @@ def test_locomp_selections_computed_side_by_side_equal_the_sequential_loop(case,
         kw['nbNonzeroCoefs'] = 8 * kw['nbNonzeroCoefs']
     rs = np.random.RandomState(case)
     xs = np.stack([x, (0.5 * x).astype(dtype), x[::-1].copy(), (x + 0.02 * rs.standard_normal(x.shape)).astype(dtype)])
-    ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)           # (default: both on -- HSCMP_LOCOMP_AHEAD=3)
+    ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)           # (default: everything on -- HSCMP_LOCOMP_AHEAD=7)
+    monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '3')                    # side by side, every group's rows at once (a quarter per wave on sparse dictionaries)
+    undeferred = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
     monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '1')                    # side by side, but a group's rows by the whole workgroup
     only_ahead = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
     monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '0')
     seq = LoCOMP().computeCoefficientsBatch(xs, D, **kw)
     assert np.array_equal(only_ahead.stats, seq.stats) and np.array_equal(only_ahead.residuals, seq.residuals)
+    assert np.array_equal(undeferred.stats, seq.stats) and np.array_equal(undeferred.residuals, seq.residuals)
     assert np.array_equal(ahead.stats, seq.stats) and np.array_equal(ahead.energies, seq.energies)
     assert int(ahead.stats[:, 4].sum()) > 4 * xs.shape[0]          # (several selections per signal)
     for b in range(xs.shape[0]):

@@ -1,6 +1,6 @@
 """Soak of LoCOMP's side-by-side path (csrc/hscmp_locomp.h, locomp_precompute): the fuzz draws of tests/test_gpu_fuzz.py::_draw with
 the signal repeated six times under varying gains and a blocked selection of 4 .. 7 blocks, so that most rounds have their selections more
-than 4W + 4 samples apart; HSCMP_LOCOMP_AHEAD=1 against =0, bit for bit (coefficients, residual, events, counters).
+than 5W + 8 samples apart; HSCMP_LOCOMP_AHEAD=7 (everything on) against =0, bit for bit (coefficients, residual, events, counters).
 usage: python tools/locomp_ahead_soak.py FIRST LAST"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,13 +23,13 @@ for i in range(lo, hi):
     if 'toleranceResidualScale' in kw: kw['toleranceResidualScale'] = float(kw['toleranceResidualScale'])
     out = {}
     try:
-        for mode in ('3', '0'):
+        for mode in ('7', '0'):
             os.environ['HSCMP_LOCOMP_AHEAD'] = mode
             c = LoCOMP(); res = c.computeCoefficientsBatch(np.stack([x, x[::-1].copy()]), D, **kw)
             out[mode] = res
     except HscmpError as ex:
         print(i, 'device error', str(ex)[:80]); continue
-    a, s = out['3'], out['0']
+    a, s = out['7'], out['0']
     ran += 1
     same = np.array_equal(a.stats, s.stats) and np.array_equal(a.residuals, s.residuals) and all((a.coefficients[b] != s.coefficients[b]).nnz == 0 for b in range(2)) \
         and all(all(np.array_equal(u, v) for u, v in zip(a.events[b], s.events[b])) for b in range(2))

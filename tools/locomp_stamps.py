@@ -31,7 +31,7 @@ sel, atoms = max(v[14], 1), v[15]
 print('workgroup 0, signal 0: %d selections, group size %.2f on average' % (sel, atoms / sel))
 print('  group sizes (bins of 8 atoms, last: >= 120):', ' '.join('%d' % v[16 + i] for i in range(16)))
 print('  all stamp slots (cycles / selection):', {i: int(v[i] / max(v[14], 1)) for i in range(64) if v[i] > 0 and i not in (14, 15) and not (16 <= i < 32)})
-names = {0: 'neighbourhood scan', 1: 'group order', 2: 'right-hand sides + Gram entries', 3: 'Cholesky + substitutions', 4: 'coefficients, subtractions, energies',
+names = {33: 'ahead: scan', 34: 'ahead: order', 35: 'ahead: normal equations', 36: 'ahead: solve', 37: 'ahead: cells / subtractions', 38: 'ahead: wait for the slowest wave', 58: 'round: lookups + spacing', 59: 'round: ahead (all of it)', 60: 'round: atom (all of it)', 0: 'neighbourhood scan', 1: 'group order', 2: 'right-hand sides + Gram entries', 3: 'Cholesky + substitutions', 4: 'coefficients, subtractions, energies',
          5: 're-correlation (all of it)', 6: 'segments marked', 10: '  window', 11: '  tiles'}
 tot = 0.0
 for i in sorted(names):
