@@ -578,6 +578,10 @@ template <typename R, int MAXSEG, bool WITH_PART = true, bool WITH_CK = true> st
     int atom_t, atom_k;
     R atom_c;
     R e_sig, e_res;
+    // LoCOMP, a selection committed by its wave alone (hscmp_locomp.h): 5, + 2 when the pursuit of this signal ends with it -- locomp_atom's
+    // result, the ONLY shared word the other waves read behind the selection's one barrier.  Two words, taken in turn: a late wave may still
+    // have to read the first selection's word when the second one's is written.  (Not in the group state: the waves' workspaces alias that.)
+    int lc_flag[2];
     // fused atom bodies: {converged, events, slots, hashed} as of the end of the last atom, written by the bookkeeping
     // lane in front of the atom's last barrier.  Every wave fetches it with ONE 16-byte read behind that barrier and
     // carries it in scalar registers (FusedCtl): beside the matrix instructions of co-resident signals each LDS round trip
@@ -976,9 +980,10 @@ constexpr int kLocompSpacing = 5;      // x W + 8 samples between any two select
 // the rows of a selection whose re-correlation waits for the end of its batch (the owning wave's registers)
 struct LocompRows { int pending, pmin, pmax; };
 template <typename R, typename Pol, typename SH, typename SY>
-__device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
-                                            char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner,
-                                            bool may_defer, LocompRows& rows);      // true: the re-correlation of its rows was deferred
+__device__ __forceinline__ int locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
+                                           char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner,
+                                           bool may_defer, LocompRows& rows);      // bit 0: the re-correlation of its rows waits; bit 2: committed by its wave
+                                                                                   // alone, and bit 1 says whether the pursuit of this signal ends with it
 template <typename R, typename Pol, typename SY>
 __device__ __forceinline__ void locomp_rows_deferred(const DevParams& P, const State<R>& S, const Sig<R>& G, const typename Pol::Args& A, char* plds,
                                                      LocompRows& rows, SY& sy);
@@ -1356,9 +1361,10 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 const bool ahead = lc_spaced && ai >= lc_first && ai < lc_first + lc_count;
                 // the rows of the selections of a batch are re-correlated TOGETHER behind its last one, one wave per selection: nothing a
                 // later selection of the batch reads or writes lies within the rows of an earlier one, or within the samples they are formed from
-                if (locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1, ahead && lc_defer, lc_rows))
-                    lc_waiting = true;
-                const bool leave = sh.skip || sh.converged;              // (uniform: read behind the atom's last barrier)
+                const int lc_rc = locomp_atom<R, Recorr>(P, S, G, sh, A, plds, wts, p, k, c, sy, lc_pre, ahead ? ai - lc_first : -1, ahead && lc_defer, lc_rows);
+                if (lc_rc & 1) lc_waiting = true;
+                // (uniform: read behind the atom's last barrier -- or handed over by it when no barrier separates it from the next selection's writes)
+                const bool leave = (lc_rc & 4) ? (lc_rc & 2) != 0 : (sh.skip || sh.converged);
                 if (lc_waiting && (leave || ai == lc_first + lc_count - 1 || ai == nsel - 1)) {
                     locomp_rows_deferred<R, Recorr>(P, S, G, A, plds, lc_rows, sy);
                     lc_waiting = false;

@@ -44,8 +44,9 @@ constexpr double kLocompRankTol = 1e-14;      // x the largest diagonal entry: n
 
 template <typename R, int NMAX = kLocompMax, int NG = kLocompLds> struct LocompLds {
     int n, cnt;                       // group size; neighbours found (may exceed the capacity)
-    int status, pad_;                 // 2: the lists and fitted coefficients were computed ahead (locomp_precompute)
-    int jmin, jmax, jout, pad2_;      // first / last position of the group; an atom whose rows reach beyond the signal (their rows are re-correlated together otherwise)
+    int status, jout;                 // 2: the lists and fitted coefficients were computed ahead (locomp_precompute); jout: see jmin
+    int jmin, jmax;                   // first / last position of the group; jout: an atom whose rows reach beyond the signal (their rows are re-correlated together otherwise)
+    int pad_[2];
     int t[NMAX], k[NMAX], si[NMAX];       // position, atom, coefficient slot (-1: none yet), group order
     int ut[NMAX], uk[NMAX], usi[NMAX];    // neighbours as found (any order)
     R a[NMAX];                  // fitted coefficients in the dictionary's dtype (:1329)
@@ -1026,7 +1027,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
 // One selected atom (p, k, c): modeling.py:1314-1383.  All threads of the signal's workgroup; the caller leaves the atom
 // loop when sh.skip or sh.converged is set afterwards.
 template <typename R, typename Pol, typename SH, typename SY>
-__device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
+__device__ __forceinline__ int locomp_atom(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A,
                                             char* plds, const R* wts, int p, int k, R c, SY& sy, const LocompPre<R>& pre, int owner,
                                             bool may_defer, LocompRows& rows)
 {
@@ -1039,8 +1040,74 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
     bool have = false, applied_ahead = false;
     if (owner >= 0) {                                            // uniform
         if (wv == owner) {
-            const int st = pre.status;
-            if (st >= 2) {
+            int st = pre.status;
+            // A group that was applied ahead and whose rows can wait is COMMITTED BY ITS WAVE ALONE -- residual, coefficient slots, event,
+            // counters, segment marks, stop rules, everything the steps below do for it, from the wave's registers -- and the workgroup
+            // meets once per selection instead of six times.
+            if (st == 3 && may_defer && !P.has_scale) {
+                const int n = pre.n;
+                const bool mine = lane < n;
+                const int tp = pre.t;
+                const int pmn = wave_min_i32(mine ? tp : INT_MAX), pmx = wave_max_i32(mine ? tp : INT_MIN);
+                const bool outside = mine && !(tp - P.off - (W - 1) >= 0 && tp + W / 2 + (W - 1) <= T - 1);      // (padding in its rows, :1028-1046)
+                if ((n > 1 || Pol::kLoneRows) && __ballot(outside) == 0 && pmx - pmn <= 2 * W) {
+                    bool full = false;
+                    if (lane == 0 && sh.nev >= P.cap) { sh.converged = 1; sh.stop = STOP_CAPACITY; sh.skip = 1; full = true; }
+                    full = __shfl(full ? 1 : 0, 0) != 0;
+                    if (!full) {
+                        const R last_e = sh.e_res;                                   // :1316
+                        if constexpr (Pol::kGroupUpdate) Pol::commit_cells(P, G, A, plds, pre.cell, pre.span);
+                        else {
+                            R* dst = G.r + (int64_t)pre.u0 * F;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int i = lane + 64 * u; if (i < pre.ulen) dst[i] = pre.span[u]; }
+                        }
+                        if (mine) {                                                  // :1336-1341, :1368 (the bookkeeping loop below, lane = atom)
+                            const int kk = pre.k;
+                            int si = pre.si;
+                            double before = 0.0;
+                            if (si < 0) {                                            // (lane 0 only)
+                                si = sh.nslots++; G.slot_t[si] = tp; G.slot_k[si] = kk;
+                                hval_store(G.hval + si, hval_load(G.head + tp)); hval_store(G.head + tp, si);
+                            }
+                            else before = G.slot_a[si];
+                            const double after = before + (double)pre.a;
+                            G.slot_a[si] = after;
+                            if (lane == 0) {
+                                if (before != 0.0) sh.ndup += 1;
+                                const int ev = sh.nev++;
+                                G.ev_t[ev] = tp; G.ev_k[ev] = kk; G.ev_c[ev] = c;
+                            }
+                            const int d = (after != 0.0 ? 1 : 0) - (before != 0.0 ? 1 : 0);
+                            if (d) atomicAdd(&sh.nnz, d);
+                            const int sg0 = max(0, tp - (W - 1)) >> P.seg_shift, sg1 = min(T - 1, tp + (W - 1)) >> P.seg_shift;
+                            for (int sg = sg0; sg <= sg1; ++sg) atomicOr(&sh.touched[sg >> 5], 1u << (sg & 31));
+                        }
+                        if (lane == 0) {                                             // :1014, :1357-1383
+                            sh.e_res = sh.e_res - pre.loss;
+                            sh.iters += 1;
+                            if ((double)sh.e_res < P.eps) { sh.converged = 1; sh.stop = STOP_ENERGY_EPS; }
+                            else if (P.l0 >= 0 && sh.nnz >= P.l0) { sh.converged = 1; sh.stop = STOP_NNZ; }
+                            else {
+                                bool done = false;
+                                if (P.has_snr) {
+                                    const R q = sh.e_sig / sh.e_res;
+                                    if ((double)q >= P.snr_ratio) { sh.converged = 1; sh.stop = STOP_SNR; done = true; }
+                                }
+                                if (!done) {
+                                    const R delta = last_e - sh.e_res;
+                                    if (fabs((double)delta) < P.eps) { sh.converged = 1; sh.stop = STOP_STALLED; }
+                                }
+                            }
+                        }
+                        rows.pending = 1; rows.pmin = pmn; rows.pmax = pmx;
+                    }
+                    if (lane == 0) sh.lc_flag[owner & 1] = 5 | ((full || sh.converged) ? 2 : 0);
+                    st = 4;
+                }
+            }
+            if (st != 4 && lane == 0) sh.lc_flag[owner & 1] = 0;
+            if (st == 2 || st == 3) {
                 if (lane < pre.n) { L.t[lane] = pre.t; L.k[lane] = pre.k; L.si[lane] = pre.si; L.a[lane] = pre.a; }
                 bool full = false;
                 if (lane == 0) {
@@ -1058,10 +1125,13 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
                     }
                 }
             }
-            if (lane == 0) L.status = st;
+            if (lane == 0 && st != 4) L.status = st;
         }
         sy.full();
-        if (sh.skip) return false;
+        // committed by its wave; its rows wait (locomp_rows_deferred).  Nothing else of the shared state is read here: the next selection's
+        // wave may be writing it already
+        if (const int fl = sh.lc_flag[owner & 1]) return fl;
+        if (sh.skip) return 0;
         have = L.status >= 2;
         applied_ahead = L.status == 3;
     }
@@ -1073,7 +1143,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
             L.jmin = INT_MAX; L.jmax = INT_MIN; L.jout = 0;
         }
         sy.full();
-        if (sh.skip) return false;
+        if (sh.skip) return 0;
     }
     int s0, e0, es0;
     centered_span(T, W, p, s0, e0, es0);
@@ -1100,7 +1170,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
     if (m > P.lg_cap - 1) {                                      // uniform: beyond the signal's scratch too (hscmp_params / HSCMP_LOCOMP_GROUP_CAP)
         if (tid == 0) { sh.converged = 1; sh.stop = STOP_GROUP; sh.skip = 1; }
         sy.full();
-        return false;
+        return 0;
     }
     // more neighbours than the LDS lists hold: the lists of this group live in the signal's global scratch
     const bool bigL = m > kCap - 1;                              // uniform
@@ -1615,7 +1685,7 @@ __device__ __forceinline__ bool locomp_atom(const DevParams& P, const State<R>& 
         }
     }
     sy.full();
-    return deferred;
+    return deferred ? 1 : 0;
 }
 
 // the rows that waited (locomp_atom, may_defer): every wave those of the selection it owns, side by side; all threads of the workgroup
