@@ -989,7 +989,8 @@ __device__ __forceinline__ void locomp_rows_deferred(const DevParams& P, const S
                                                      LocompRows& rows, SY& sy);
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
-                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy);
+                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre,
+                                                  LocompRows& rows, SY& sy);
 
 template <typename R, typename Recorr>
 __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd) void iterate_kernel(DevParams P, State<R> S, typename Recorr::Args A)
@@ -1356,7 +1357,8 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 // wave each (locomp_precompute), then the applications in order
                 if (lc_spaced && ai == lc_first + lc_count && nsel - ai >= 2) {
                     lc_first = ai; lc_count = min(kWaves, nsel - ai);
-                    locomp_precompute<R, Recorr>(P, S, G, sh, A, plds, ord_t, ord_k, ord_c, lc_first, lc_count, lc_pre, sy);
+                    locomp_precompute<R, Recorr>(P, S, G, sh, A, plds, ord_t, ord_k, ord_c, lc_first, lc_count, lc_pre, lc_rows, sy);
+                    lc_waiting = false;                  // (rows of the previous batch that waited were its waves' first job)
                 }
                 const bool ahead = lc_spaced && ai >= lc_first && ai < lc_first + lc_count;
                 // the rows of the selections of a batch are re-correlated TOGETHER behind its last one, one wave per selection: nothing a
@@ -1365,7 +1367,9 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
                 if (lc_rc & 1) lc_waiting = true;
                 // (uniform: read behind the atom's last barrier -- or handed over by it when no barrier separates it from the next selection's writes)
                 const bool leave = (lc_rc & 4) ? (lc_rc & 2) != 0 : (sh.skip || sh.converged);
-                if (lc_waiting && (leave || ai == lc_first + lc_count - 1 || ai == nsel - 1)) {
+                // (when another batch of this round follows, its computations ahead take the rows along: neither reads what the other writes,
+                //  and a wave with many rows to do may well own a small group next)
+                if (lc_waiting && (leave || ai == nsel - 1 || (ai == lc_first + lc_count - 1 && nsel - (ai + 1) < 2))) {
                     locomp_rows_deferred<R, Recorr>(P, S, G, A, plds, lc_rows, sy);
                     lc_waiting = false;
                 }

@@ -818,7 +818,8 @@ template <typename R, int NW> struct WaveGroup {
 };
 template <typename R, typename Pol, typename SH, typename SY>
 __device__ __forceinline__ void locomp_precompute(const DevParams& P, const State<R>& S, const Sig<R>& G, SH& sh, const typename Pol::Args& A, char* plds,
-                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre, SY& sy)
+                                                  const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre,
+                                                  LocompRows& rows, SY& sy)
 {
     constexpr int NW = Pol::kFastGroup >= 32 ? 32 : 16;
     using WG = WaveGroup<R, NW>;
@@ -833,6 +834,9 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // rows of the previous batch that still wait (locomp_atom, may_defer): this wave's first (its window, where the policy needs one, lies in
+    // the wave's own workspace)
+    if constexpr (Pol::kUnionRows) if (rows.pending) { Pol::rows_of_wave(P, S, G, A, plds, rows.pmin, rows.pmax); rows.pending = 0; }
     if (wv < count) {
         WG& w = *reinterpret_cast<WG*>(reinterpret_cast<char*>(&L) + (size_t)wv * kStride);
         const int p = ord_t[first + wv], k = ord_k[first + wv];
