@@ -141,6 +141,15 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
             r0 += 1;
         }
     }
+    // the calling wave's slot, lent to locomp_precompute between two uses by the row pipeline (nullptr: there are no slots)
+    static __device__ __forceinline__ char* wave_scratch(const DevParams& P, const Args& A0, char* lds, size_t& bytes)
+    {
+        const Args A = dict_view(P, A0, lds + sparse_lds_bytes<R>(A0.caps));
+        size_t sb; RpSparseCaps c{};
+        if (!wave_slots(A0, A, sb, c)) { bytes = 0; return nullptr; }
+        bytes = sb;
+        return lds + (size_t)(ltid() >> 6) * sb;
+    }
     // deferred rows (locomp_rows_deferred): ALL rows of one selection's group by the wave that owns it
     static __device__ __forceinline__ bool can_defer_rows(const DevParams& P, const Args& A0, char* lds)
     {
@@ -809,11 +818,12 @@ __device__ __forceinline__ double strided8_dot(const R* __restrict__ a, const R*
 // applications (coefficient slots, residual, re-correlation, stop rules) then follow in order, each picking its lists and fitted
 // coefficients up from its wave's registers.  Nothing is written but wave-private LDS, so a round that stops half-way simply drops the rest.
 // The four workspaces alias the memory of the group state the applications go through (Pol::Lds): results leave through registers.
-template <typename R, int NW> struct WaveGroup {
+// (GRAM_INSIDE false: the Gram matrix lives in scratch the policy lends the wave -- Pol::wave_scratch -- and the lists may be longer)
+template <typename R, int NW, bool GRAM_INSIDE = true> struct WaveGroup {
     int n, pad_;
     int t[NW], k[NW], si[NW], ut[NW], uk[NW], usi[NW];
     double b[NW];
-    double g[NW * (NW + 1) / 2];
+    double g[GRAM_INSIDE ? NW * (NW + 1) / 2 : 1];
     R a[NW];
 };
 template <typename R, typename Pol, typename SH, typename SY>
@@ -821,8 +831,11 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                                                   const int* ord_t, const int* ord_k, const R* ord_c, int first, int count, LocompPre<R>& pre,
                                                   LocompRows& rows, SY& sy)
 {
-    constexpr int NW = Pol::kFastGroup >= 32 ? 32 : 16;
-    using WG = WaveGroup<R, NW>;
+    // sparse policy: the Gram matrix (and the pair lists after it) in the wave's slot of the row pipeline, 12 KB at BASELINE config 5 -- groups
+    // of up to 54 atoms then (one selection out of six of its third level has more than 32)
+    constexpr bool kLent = Pol::kGroupUpdate;
+    constexpr int NW = kLent ? 64 : Pol::kFastGroup >= 32 ? 32 : 16;
+    using WG = WaveGroup<R, NW, !kLent>;
     constexpr size_t kStride = (sizeof(typename Pol::Lds) / kWaves) & ~(size_t)15;
     static_assert(sizeof(WG) <= kStride, "four wave workspaces must fit the group state they alias");
     typename Pol::Lds& L = Pol::group(P, A, plds);
@@ -859,7 +872,18 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
             }
         wave_sync();
         const int m = __builtin_amdgcn_readfirstlane(w.n);
-        bool ok = m <= NW - 1;                                       // (a larger group: the selection goes the usual way)
+        double* wg = w.g;                                            // the Gram matrix of this wave's group
+        size_t wg_bytes = sizeof(w.g);
+        if constexpr (kLent) {
+            wg = reinterpret_cast<double*>(Pol::wave_scratch(P, A, plds, wg_bytes));
+            if (!wg) {                                               // (no slots: what the workspace leaves behind the lists -- 27 atoms)
+                constexpr size_t used = (sizeof(WG) + 15) & ~(size_t)15;
+                wg = reinterpret_cast<double*>(reinterpret_cast<char*>(&w) + used);
+                wg_bytes = kStride - used;
+            }
+        }
+        // (a larger group: the selection goes the usual way)
+        bool ok = m <= NW - 1 && wg != nullptr && (size_t)(m + 1) * (m + 2) / 2 * sizeof(double) <= wg_bytes;
         if (ok) {
             if (lane < m) {                                          // group order: (position, atom) ascending behind the selected atom
                 const long long key = ((long long)w.ut[lane] << 32) | (unsigned)w.uk[lane];
@@ -895,7 +919,7 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                                 for (int e2 = ej0; e2 < ej1; ++e2)
                                     if (nzwf[e2] == want) acc += (double)nzv[e] * (double)nzv[e2];
                             }
-                            w.g[i * (i + 1) / 2 + j] = acc;
+                            wg[i * (i + 1) / 2 + j] = acc;
                         }
                     }
                 } else {                                                 // dense dictionary: eight lanes per item
@@ -922,13 +946,14 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
                             }
                         }
                         acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-                        if (sub == 0) { if (it < n) w.b[it] = acc; else w.g[i * (i + 1) / 2 + j] = acc; }
+                        if (sub == 0) { if (it < n) w.b[it] = acc; else wg[i * (i + 1) / 2 + j] = acc; }
                     }
                 }
                 wave_sync();
-                if (n <= 8) ok = locomp_fast_solve<8>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
-                else if (n <= 16) ok = locomp_fast_solve<16>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
-                else ok = locomp_fast_solve<NW>(lds_off(w.g), lds_off(w.b), n, lds_off(w.b));
+                if (n <= 8) ok = locomp_fast_solve<8>(lds_off(wg), lds_off(w.b), n, lds_off(w.b));
+                else if (n <= 16) ok = locomp_fast_solve<16>(lds_off(wg), lds_off(w.b), n, lds_off(w.b));
+                else if (!kLent || n <= 32) ok = locomp_fast_solve<(kLent ? 32 : NW)>(lds_off(wg), lds_off(w.b), n, lds_off(w.b));
+                else ok = locomp_fast_solve<Pol::kFastGroup>(lds_off(wg), lds_off(w.b), n, lds_off(w.b));
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 wave_sync();
             }
@@ -939,10 +964,10 @@ __device__ __forceinline__ void locomp_precompute(const DevParams& P, const Stat
             // Sparse dictionary with row lists: the group's cells and its energy loss too (LocompSparse::cells_ahead), in the LDS the normal
             // equations have left; applied by the owning wave when the selection's turn comes.
             if constexpr (Pol::kGroupUpdate) {
-                if (ok) {
-                    static_assert(sizeof(w.g) >= 33 * sizeof(int) + 128 * (sizeof(int) + sizeof(R)) + 16, "the pair lists live in the Gram matrix's LDS");
-                    int* off = reinterpret_cast<int*>(w.g);
-                    R* prod = reinterpret_cast<R*>(reinterpret_cast<char*>(w.g) + ((33 * sizeof(int) + 15) & ~(size_t)15));
+                constexpr size_t kOffBytes = ((NW + 1) * sizeof(int) + 15) & ~(size_t)15;            // off[n + 1], then prod[128], key[128]
+                if (ok && wg_bytes >= kOffBytes + 128 * (sizeof(int) + sizeof(R))) {
+                    int* off = reinterpret_cast<int*>(wg);
+                    R* prod = reinterpret_cast<R*>(reinterpret_cast<char*>(wg) + kOffBytes);
                     int* key = reinterpret_cast<int*>(prod + 128);
                     R loss;
                     if (Pol::cells_ahead(P, G, A, plds, n, w.t, w.k, w.b, c, off, key, prod, lane, pre.cell, pre.span, loss)) {

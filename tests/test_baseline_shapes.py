@@ -296,6 +296,36 @@ def test_config5_generated_three_level_dictionary(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('config,B', [(5, 6), (4, 12)])
+def test_locomp_at_baseline_shapes_side_by_side_equals_sequential(config, B, monkeypatch):
+    """The reference's default method on BASELINE configs[4] / [3] at their FULL signal length (T = 65536, ten blocks): everything the
+    device loop does beside the selection-by-selection order -- groups computed ahead one wave each (up to 54 atoms on the sparse levels,
+    their Gram matrices in the waves' row-pipeline slots), committed by their waves alone, rows re-correlated a batch at a time
+    (HSCMP_LOCOMP_AHEAD=7, the default) -- against HSCMP_LOCOMP_AHEAD=0, level by level on the same inputs: stop reasons, counters, event
+    records, coefficients and residuals bit for bit.  The third level of config 5 is where groups of more than 32 atoms occur."""
+    import bench_hsc
+    from hsc_amd.modeling import LoCOMP
+    mlds, xs, kw, _ = bench_hsc.build_workload(config, B, 65536, 0, 17)
+    inp = xs
+    for level in range(mlds.getNbLevels()):
+        D = mlds.getRawDictionary(level)
+        nbS = D.shape[0] - mlds.countsNoSingletons[level]
+        w = np.ones((D.shape[0],), dtype=D.dtype); w[:nbS] = kw.get('singletonWeight', 0.5)
+        args = dict(toleranceSnr=kw['toleranceSnr'][level], nbBlocks=kw['nbBlocks'], weights=w)
+        monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '7')
+        fast = LoCOMP().computeCoefficientsBatch(inp, D, **args)
+        monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '0')
+        seq = LoCOMP().computeCoefficientsBatch(inp, D, **args)
+        assert np.array_equal(fast.stats, seq.stats), level
+        assert np.array_equal(fast.residuals, seq.residuals), level
+        for b in range(B):
+            assert (fast.coefficients[b] != seq.coefficients[b]).nnz == 0, (level, b)
+            assert all(np.array_equal(u, v) for u, v in zip(fast.events[b], seq.events[b])), (level, b)
+        assert int(fast.stats[:, 4].min()) > 100, level                  # (hundreds of selections per signal)
+        inp = np.stack([c.toarray() for c in fast.coefficients], axis=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('method', ['cmp', 'locomp'])
 def test_config4_dims_several_chunks_through_the_device_epilogue(method):
     """The memory-budget path that anything larger than config 4 takes by default: levels >= 1 walk the batch in chunks (their dense
