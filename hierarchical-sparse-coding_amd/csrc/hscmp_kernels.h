@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(kThreads * Recorr::kGroup, Recorr::kMinWavesPerSimd
         }
         // =========================== apply the selected atoms (:1101-1142) ===========================
         bool fused_stop = false;       // uniform: apply_atom's return value is read after its last barrier
-        // LoCOMP: are the selections of this round more than 4W + 4 samples apart, every pair of them?  (hscmp_locomp.h)
+        // LoCOMP: are the selections of this round more than 5W + 8 samples apart, every pair of them?  (hscmp_locomp.h)
         bool lc_spaced = false;
         int lc_first = 0, lc_count = 0;
         LocompPre<R> lc_pre{};

@@ -810,14 +810,19 @@ __device__ __forceinline__ double strided8_dot(const R* __restrict__ a, const R*
 }
 
 // ---- the selections of a blocked round side by side, as far as they do not depend on each other -------------------------------
-// The atoms of a blocked round (:908-963) are applied one after the other (:1314), but when they lie more than 4W + 4 samples apart
-// nothing one of them does reaches what another one's neighbourhood, normal equations and re-fit read: neighbours come from positions
-// within 1.5 W of the selected atom, their spans reach 2 W, and a selection changes residual and coefficient slots within 2 W of itself.
-// (BASELINE configs 4 / 5: ten blocks over 65536 samples, 6 500 samples apart.)  So that part -- half of a selection's cycles, most of it
-// one wave's work anyway -- is computed for up to four selections AT ONCE, one wave each, before any of them is applied; the
-// applications (coefficient slots, residual, re-correlation, stop rules) then follow in order, each picking its lists and fitted
-// coefficients up from its wave's registers.  Nothing is written but wave-private LDS, so a round that stops half-way simply drops the rest.
-// The four workspaces alias the memory of the group state the applications go through (Pol::Lds): results leave through registers.
+// The atoms of a blocked round (:908-963) are applied one after the other (:1314), but when they lie more than 5W + 8 samples apart
+// nothing one of them does reaches what another one reads: neighbours come from positions within W of the selected atom, their spans
+// reach 1.5 W, the rows re-correlated for a group lie within 2 W and are formed from samples within 2.5 W -- against residual and
+// coefficient slots changed within 1.5 W.  (BASELINE configs 4 / 5: ten blocks over 65536 samples, 6 500 samples apart.)  Three things
+// follow, each switched by a bit of HSCMP_LOCOMP_AHEAD and each bit-identical to the selection-by-selection loop:
+//  * locomp_precompute: neighbourhood, normal equations, re-fit -- and the subtractions with their local energies, on a private copy of
+//    the span (dense) or as a list of final cell values (sparse) -- of up to four selections AT ONCE, one wave each, before any of them is
+//    applied.  Nothing is written but wave-private LDS (four workspaces that alias the group state Pol::Lds; the sparse policy lends each
+//    wave its slot of the row pipeline for the Gram matrix: groups of up to 54 atoms); results leave through registers.
+//  * locomp_atom's first branch: such a group is COMMITTED BY ITS WAVE ALONE when its turn comes -- residual, coefficient slots, event,
+//    counters, segment marks, stop rules -- and the workgroup meets once per selection; a round that stops half-way drops the rest.
+//  * locomp_rows_deferred: the rows of the batch are re-correlated behind its last selection (or as the first job of the next batch's
+//    computations ahead), one wave per selection.
 // (GRAM_INSIDE false: the Gram matrix lives in scratch the policy lends the wave -- Pol::wave_scratch -- and the lists may be longer)
 template <typename R, int NW, bool GRAM_INSIDE = true> struct WaveGroup {
     int n, pad_;

@@ -27,11 +27,12 @@ for level in range(LEVEL + 1):
 lib.hscmp_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
 print('config', CONFIG, 'level', LEVEL, D.shape, res.variant, 'loop %.1f ms' % res.kernel_ms[2], 'selections per signal %.0f' % res.stats[:, 4].mean())
-sel, atoms = max(v[14], 1), v[15]
-print('workgroup 0, signal 0: %d selections, group size %.2f on average' % (sel, atoms / sel))
-print('  group sizes (bins of 8 atoms, last: >= 120):', ' '.join('%d' % v[16 + i] for i in range(16)))
-print('  all stamp slots (cycles / selection):', {i: int(v[i] / max(v[14], 1)) for i in range(64) if v[i] > 0 and i not in (14, 15) and not (16 <= i < 32)})
-names = {33: 'ahead: scan', 34: 'ahead: order', 35: 'ahead: normal equations', 36: 'ahead: solve', 37: 'ahead: cells / subtractions', 38: 'ahead: wait for the slowest wave', 58: 'round: lookups + spacing', 59: 'round: ahead (all of it)', 60: 'round: atom (all of it)', 0: 'neighbourhood scan', 1: 'group order', 2: 'right-hand sides + Gram entries', 3: 'Cholesky + substitutions', 4: 'coefficients, subtractions, energies',
+full, atoms = max(v[14], 1), v[15]
+sel = max(float(res.stats[0, 4]), 1.0)
+print('workgroup 0, signal 0: %d selections, %d of them through the whole atom body (the others: computed ahead and committed by their wave), their group size %.2f on average' % (sel, full, atoms / full))
+print('  group sizes of those (bins of 8 atoms, last: >= 120):', ' '.join('%d' % v[16 + i] for i in range(16)))
+print('  all stamp slots (cycles / selection):', {i: int(v[i] / sel) for i in range(64) if v[i] > 0 and i not in (14, 15) and not (16 <= i < 32)})
+names = {33: 'ahead: scan', 34: 'ahead: order', 35: 'ahead: normal equations', 36: 'ahead: solve', 37: 'ahead: cells / subtractions', 38: 'ahead: wait for the slowest wave', 58: 'round: lookups + spacing', 59: 'round: ahead (all of it)', 60: 'round: atom (all of it)', 62: 'round: rows that waited (behind the last batch)', 63: 'ahead: rows that waited', 0: 'neighbourhood scan', 1: 'group order', 2: 'right-hand sides + Gram entries', 3: 'Cholesky + substitutions', 4: 'coefficients, subtractions, energies',
          5: 're-correlation (all of it)', 6: 'segments marked', 10: '  window', 11: '  tiles'}
 tot = 0.0
 for i in sorted(names):
