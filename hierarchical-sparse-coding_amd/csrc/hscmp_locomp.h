@@ -99,7 +99,8 @@ template <typename R> struct LocompSparse : SparseRecorr<R, false> {
                                                         //  this policy has the registers for the whole LDS-resident range; lane n holds b)
     static constexpr bool kWaveApply = false;           // (update_residual keeps the row lists: the workgroup form)
     static constexpr bool kUnionRows = true;
-    static constexpr bool kLoneRows = false;            // (a lone atom goes through the workgroup-wide rows with the window copy its subtraction left)
+    static constexpr bool kLoneRows = true;             // (a lone interior atom too: computed ahead, committed by its wave, its rows through the per-wave pipeline --
+                                                        //  three selections in four at BASELINE config 4's second level)
     static constexpr int kMaxGroup = kLocompMax;
     using Lds = LocompLds<R>;
     using Base = SparseRecorr<R, false>;
