@@ -296,15 +296,20 @@ def test_config5_generated_three_level_dictionary(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('config,B', [(5, 6), (4, 12)])
-def test_locomp_at_baseline_shapes_side_by_side_equals_sequential(config, B, monkeypatch):
+@pytest.mark.parametrize('config,B,pack', [(5, 6, None), (4, 12, None), (4, 16, '4')])
+def test_locomp_at_baseline_shapes_side_by_side_equals_sequential(config, B, pack, monkeypatch):
     """The reference's default method on BASELINE configs[4] / [3] at their FULL signal length (T = 65536, ten blocks): everything the
     device loop does beside the selection-by-selection order -- groups computed ahead one wave each (up to 54 atoms on the sparse levels,
     their Gram matrices in the waves' row-pipeline slots), committed by their waves alone, rows re-correlated a batch at a time
     (HSCMP_LOCOMP_AHEAD=7, the default) -- against HSCMP_LOCOMP_AHEAD=0, level by level on the same inputs: stop reasons, counters, event
-    records, coefficients and residuals bit for bit.  The third level of config 5 is where groups of more than 32 atoms occur."""
+    records, coefficients and residuals bit for bit.  The third level of config 5 is where groups of more than 32 atoms occur; the third case
+    runs config 4 with FOUR signals per workgroup on its first level (HSCMP_LOCOMP_PACK=4, what the full batch of 1024 takes: each signal's
+    four waves meet at a counter in LDS instead of the hardware barrier and a wave can be a whole phase late -- the arrangement under which a
+    selection's verdict must survive the next one's)."""
     import bench_hsc
     from hsc_amd.modeling import LoCOMP
+    if pack:
+        monkeypatch.setenv('HSCMP_LOCOMP_PACK', pack)
     mlds, xs, kw, _ = bench_hsc.build_workload(config, B, 65536, 0, 17)
     inp = xs
     for level in range(mlds.getNbLevels()):
@@ -316,6 +321,8 @@ def test_locomp_at_baseline_shapes_side_by_side_equals_sequential(config, B, mon
         fast = LoCOMP().computeCoefficientsBatch(inp, D, **args)
         monkeypatch.setenv('HSCMP_LOCOMP_AHEAD', '0')
         seq = LoCOMP().computeCoefficientsBatch(inp, D, **args)
+        if pack and level == 0:
+            assert 'mfma' in fast.variant, fast.variant
         assert np.array_equal(fast.stats, seq.stats), level
         assert np.array_equal(fast.residuals, seq.residuals), level
         for b in range(B):
